@@ -1,0 +1,117 @@
+/*
+ * mipx.h -- C ABI of the MI355X-native branch-and-bound node engine (libmipx.so).
+ *
+ * The reference (spkelle2/simple_mip_solver) has no FFI: its node hot path calls COIN-OR Clp
+ * through the cylp Python wrapper.  Each entry point below replaces one such call site; the
+ * Python mirror of the reference's Node/BranchAndBound plugin surface in
+ * simple_mip_solver_amd/ binds these through ctypes (see INTEGRATION.md for the stub a
+ * maintainer of the reference would add).
+ *
+ * Conventions
+ *   - Problem form on the hot path (simple_mip_solver/nodes/base_node.py:111-112,
+ *     algorithms/base_algorithm.py:48-61):  min c'x  s.t.  A x >= b,  l <= x <= u,  l >= 0.
+ *   - A is dense row-major f64 (m x n).  u may be +inf.
+ *   - Basis/status codes are Clp's, as read by the reference (base_node.py:530):
+ *     1 basic, 2 at upper, 3 at lower (anything else is treated as at lower).
+ *     Layout: n structural codes then m row (slack) codes -- the concatenation of the pair
+ *     returned by CyClpSimplex.getBasisStatus() (base_node.py:589).
+ *   - LP status codes are Clp's (base_node.py:274-275, pseudo_cost.py:86):
+ *     0 optimal, 1 primal infeasible, 2 dual infeasible/unbounded, 3 iteration limit.
+ *   - Every function returns 0 on success or a negative MIPX_E* code; nothing throws across
+ *     the ABI; mipx_last_error() returns a description of the last failure on that context.
+ *   - Host buffers stay owned by the caller; the library keeps no host pointer past return.
+ *   - A context is bound to one GPU and one HIP stream and is not thread-safe.
+ *   - There is NO CPU fallback: without a usable gfx950 device mipx_ctx_create fails.
+ */
+#ifndef MIPX_H
+#define MIPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIPX_OK 0
+#define MIPX_EINVAL -1    /* bad argument */
+#define MIPX_ENODEV -2    /* no usable HIP device */
+#define MIPX_EHIP -3      /* HIP runtime error (see mipx_last_error) */
+#define MIPX_ETOOBIG -4   /* (m, n) exceeds what the on-chip tableau kernels support */
+#define MIPX_ENOMEM -5
+
+typedef struct mipx_ctx mipx_ctx;
+typedef struct mipx_problem mipx_problem;
+
+/* ABI version of this header (bumped on any signature change). */
+int mipx_abi_version(void);
+
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+int mipx_device_count(void);
+
+/* Create a context on HIP device `device` with its own stream. */
+int mipx_ctx_create(int device, mipx_ctx **out);
+void mipx_ctx_destroy(mipx_ctx *ctx);
+const char *mipx_last_error(const mipx_ctx *ctx);
+int mipx_ctx_sync(mipx_ctx *ctx);
+
+/*
+ * Upload the data shared by every node of one tree: replaces the reference keeping (A,b,c)
+ * inside every node's CyClpSimplex (base_node.py:74, rebuilt per child at :592-607).
+ */
+int mipx_problem_create(mipx_ctx *ctx, int m, int n, const double *A_rowmajor, const double *b,
+                        const double *c, mipx_problem **out);
+void mipx_problem_destroy(mipx_problem *p);
+
+/*
+ * Batched node LP relaxation: replaces `self.lp.dual()` + the status/objective/solution reads
+ * of BaseNode._bound_lp (base_node.py:273-280) for `batch` nodes at once, and the truncated
+ * solves of BaseNode._strong_branch (base_node.py:645-646) when max_iter > 0.
+ *
+ *   l, u        batch x n   per-node variable bounds (base_node.py:595-600)
+ *   vstat_in    batch x (n+m) warm-start basis (base_node.py:608 setBasisStatus) or NULL = cold
+ *   max_iter    <= 0: run to termination; > 0: lp.maxNumIteration (base_node.py:645)
+ *   status      batch       Clp status code
+ *   obj         batch       c'x (+inf if status 1, -inf if status 2)
+ *   x           batch x n   primalVariableSolution
+ *   y           batch x m   dualConstraintSolution (row duals; 0 where the row's slack is basic)
+ *   vstat_out   batch x (n+m) getBasisStatus
+ *   iters       batch       dual simplex iterations (CyClpSimplex.iteration)
+ *   npivots     batch       tableau pivots incl. the warm-start refactorisation
+ * Any output pointer may be NULL.  All pointers are HOST pointers.
+ */
+int mipx_lp_solve_batch(mipx_problem *p, int batch, const double *l, const double *u,
+                        const int8_t *vstat_in, int max_iter, int32_t *status, double *obj,
+                        double *x, double *y, int8_t *vstat_out, int32_t *iters,
+                        int32_t *npivots);
+
+/*
+ * Device-resident variant (inputs and outputs already in HBM; nothing crosses PCIe).
+ * Pointers are DEVICE pointers obtained from mipx_dev_alloc.  Asynchronous on the context
+ * stream; call mipx_ctx_sync before reading results back.
+ */
+int mipx_lp_solve_batch_dev(mipx_problem *p, int batch, const double *l, const double *u,
+                            const int8_t *vstat_in, int max_iter, int32_t *status, double *obj,
+                            double *x, double *y, int8_t *vstat_out, int32_t *iters,
+                            int32_t *npivots);
+
+/* Device memory owned by the library, for the device-resident entry points. */
+int mipx_dev_alloc(mipx_ctx *ctx, size_t bytes, void **dptr);
+int mipx_dev_free(mipx_ctx *ctx, void *dptr);
+int mipx_memcpy_h2d(mipx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int mipx_memcpy_d2h(mipx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/*
+ * HIP-event timer on the context stream (the stream the kernels are launched on), used by
+ * bench.py for the roofline figure.  stop returns elapsed milliseconds since start.
+ */
+int mipx_timer_start(mipx_ctx *ctx);
+int mipx_timer_stop(mipx_ctx *ctx, float *ms);
+
+/* Name of the kernel instantiation that (m, n) dispatches to, e.g. "lp_dual_simplex<16,32,8,8>". */
+int mipx_kernel_name(int m, int n, char *buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPX_H */

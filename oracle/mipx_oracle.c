@@ -1,0 +1,412 @@
+/*
+ * mipx_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * A plain-C restatement of the per-node hot path of spkelle2/simple_mip_solver:
+ *   - the node LP relaxation that the reference delegates to Clp through
+ *     `self.lp.dual()` (simple_mip_solver/nodes/base_node.py:259-286, :273) and the
+ *     truncated strong-branching solves (base_node.py:629-647),
+ *   - most-fractional index selection (base_node.py:544-562),
+ *   - pseudo-cost bookkeeping and scoring (nodes/branch/pseudo_cost.py:68-133),
+ *   - tableau / Gomory mixed-integer cuts (base_node.py:468-530),
+ *   - numerically safe cut rounding (utils/floating_point.py:11-167),
+ *   - cut selection (base_node.py:387-466).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library.  The product (simple_mip_solver_amd/) never links, imports or calls it.
+ *
+ * PARITY STATUS.  The simplex arithmetic of the reference lives in third-party COIN-OR
+ * Clp reached via cylp (un-vendored, version unpinned: environment.yml:7,15-16), which is
+ * absent from this image.  The LP part of this oracle is therefore a restatement of the
+ * textbook bounded dual simplex that `lp.dual()` stands for, pinned by the reference's own
+ * known-answer tests at the Clp boundary (test_base_node.py:394-437, :681-684, :711-755,
+ * test_branch_and_bound.py:48-322; see tests/test_oracle_known_answers.py) and by
+ * independent HiGHS optima (tests/golden/example_models_optima.json).  The pure-Python
+ * arithmetic (Gomory, safe cuts, selection, branching, pseudo-costs) is pinned by golden
+ * vectors generated from the reference's own code (tests/golden/make_golden.py).
+ *
+ * CANONICAL ALGORITHM ("mipx dual simplex", also followed bit-for-bit by the HIP kernel):
+ *   variables 0..n-1 structural (l <= x <= u, u may be +inf), n..n+m-1 slacks s = Ax - b >= 0.
+ *   condensed tableau  x_B + T x_N = beta0,  reduced costs d_N, carried through pivots.
+ *   0. T = -A, beta0 = -b, d = c, basis = all slacks.
+ *   1. refactor: every structural marked basic in the warm-start status is pivoted in
+ *      (increasing index) on the row of largest |T_iq| among rows whose basic slack is marked
+ *      nonbasic (fallback: any slack row); ties -> lowest row.
+ *   2. nonbasic bound choice: d_j < -DTOL -> upper (a symbolic "fake" upper M if u = inf),
+ *      d_j > DTOL -> lower, else keep the warm-start side.  Basic values are kept as
+ *      two-component numbers a + b*M; beta = beta0 - T v_N with a fold-in-half summation tree.
+ *   3. dual simplex: leaving row = largest bound violation (M-level beats real level, ties ->
+ *      lowest variable index); Harris two-pass ratio test (ties -> lowest variable index);
+ *      rank-1 tableau update with explicit fma.
+ *   4. status 0 optimal / 1 primal infeasible / 2 unbounded (optimum depends on M) /
+ *      3 iteration limit -- the Clp codes the reference reads (base_node.py:274-275,
+ *      pseudo_cost.py:86).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MIPX_PTOL 1e-7   /* primal feasibility tolerance (Clp default primalTolerance) */
+#define MIPX_DTOL 1e-7   /* dual feasibility tolerance (Clp default dualTolerance)     */
+#define MIPX_PIVTOL 1e-9 /* smallest acceptable |pivot|                                 */
+#define MIPX_BTOL 1e-9   /* zero test on the M component                                */
+
+#define ST_BASIC 1
+#define ST_UPPER 2
+#define ST_LOWER 3
+
+static int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+/* fold-in-half summation tree over a power-of-two length buffer (destroys p) */
+static double fold_sum(double *p, int n2) {
+    for (int h = n2 / 2; h >= 1; h /= 2)
+        for (int j = 0; j < h; j++) p[j] = p[j] + p[j + h];
+    return p[0];
+}
+
+typedef struct {
+    int m, n;
+    double *T;      /* m x n */
+    double *beta0;  /* m */
+    double *d;      /* n */
+    int *bvar;      /* m : variable basic in row i */
+    int *nvar;      /* n : variable nonbasic in column j */
+} tab_t;
+
+/* condensed-tableau pivot on (r,q); also transforms beta0 and d */
+static void tab_pivot(tab_t *t, int r, int q) {
+    const int m = t->m, n = t->n;
+    double *T = t->T;
+    const double p = T[(size_t)r * n + q];
+    const double pinv = 1.0 / p;
+    /* rho_j = T_rj / p, alpha_i = T_iq */
+    double *rho = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+    for (int j = 0; j < n; j++) rho[j] = T[(size_t)r * n + j] / p;
+    rho[n] = t->beta0[r] / p;
+    for (int i = 0; i < m; i++) {
+        if (i == r) continue;
+        const double a = T[(size_t)i * n + q];
+        double *Ti = T + (size_t)i * n;
+        for (int j = 0; j < n; j++)
+            if (j != q) Ti[j] = fma(-a, rho[j], Ti[j]);
+        Ti[q] = -a / p;
+        t->beta0[i] = fma(-a, rho[n], t->beta0[i]);
+    }
+    {
+        const double a = t->d[q];
+        for (int j = 0; j < n; j++)
+            if (j != q) t->d[j] = fma(-a, rho[j], t->d[j]);
+        t->d[q] = -a / p;
+    }
+    for (int j = 0; j < n; j++) T[(size_t)r * n + j] = rho[j];
+    T[(size_t)r * n + q] = pinv;
+    t->beta0[r] = rho[n];
+    int tmp = t->bvar[r]; t->bvar[r] = t->nvar[q]; t->nvar[q] = tmp;
+    free(rho);
+}
+
+/*
+ * Solve  min c'x  s.t.  A x >= b,  l <= x <= u   (A row-major m x n, u may be +inf, l finite).
+ * vstat_in: n+m Clp status codes (1 basic, 2 at upper, 3 at lower, anything else = at lower)
+ *           or NULL for a cold start from the slack basis.
+ * max_iter <= 0: no limit other than the internal cap.
+ * Outputs: status (0/1/2/3), obj (c'x; +inf if infeasible, -inf if unbounded), x[n],
+ *          y[m] row duals, dj[n] reduced costs of structurals (0 for basic), vstat_out[n+m],
+ *          iters (dual simplex iterations), npivots (refactor + simplex pivots).
+ * Any output pointer may be NULL.
+ */
+int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const double *c,
+                         const double *l, const double *u, const int8_t *vstat_in, int max_iter,
+                         int32_t *status_out, double *obj_out, double *x_out, double *y_out,
+                         double *dj_out, int8_t *vstat_out, int32_t *iters_out,
+                         int32_t *npivots_out) {
+    if (m < 0 || n <= 0) return -1;
+    tab_t t;
+    t.m = m; t.n = n;
+    t.T = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1) * n);
+    t.beta0 = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    t.d = (double *)malloc(sizeof(double) * (size_t)n);
+    t.bvar = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    t.nvar = (int *)malloc(sizeof(int) * (size_t)n);
+    const int nv = n + m;
+    int8_t *atup = (int8_t *)calloc((size_t)nv, 1);       /* warm-start side */
+    int8_t *wantb = (int8_t *)calloc((size_t)nv, 1);      /* warm-start basic flag */
+    int8_t *nb_up = (int8_t *)calloc((size_t)n, 1);       /* per column: 0 lower, 1 upper, 2 fake upper */
+    double *ba = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    double *bb = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    const int n2 = next_pow2(n);
+    double *buf = (double *)malloc(sizeof(double) * (size_t)n2);
+    double *va = (double *)malloc(sizeof(double) * (size_t)n);
+    double *vb = (double *)malloc(sizeof(double) * (size_t)n);
+
+    for (int i = 0; i < m; i++) {
+        for (int j = 0; j < n; j++) t.T[(size_t)i * n + j] = -A[(size_t)i * n + j];
+        t.beta0[i] = -b[i];
+        t.bvar[i] = n + i;
+    }
+    for (int j = 0; j < n; j++) { t.d[j] = c[j]; t.nvar[j] = j; }
+    int npiv = 0;
+
+    /* 1. refactor to the warm-start basis */
+    if (vstat_in) {
+        for (int v = 0; v < nv; v++) {
+            wantb[v] = (vstat_in[v] == ST_BASIC);
+            atup[v] = (vstat_in[v] == ST_UPPER);
+        }
+        for (int q = 0; q < n; q++) {
+            if (!wantb[q]) continue;
+            int best = -1; double bestv = MIPX_PIVTOL;
+            for (int i = 0; i < m; i++) {
+                int bv = t.bvar[i];
+                if (bv < n || wantb[bv]) continue;
+                double a = fabs(t.T[(size_t)i * n + q]);
+                if (a > bestv) { bestv = a; best = i; }
+            }
+            if (best < 0) {
+                for (int i = 0; i < m; i++) {
+                    int bv = t.bvar[i];
+                    if (bv < n) continue;
+                    double a = fabs(t.T[(size_t)i * n + q]);
+                    if (a > bestv) { bestv = a; best = i; }
+                }
+            }
+            if (best < 0) continue; /* singular: stays nonbasic */
+            tab_pivot(&t, best, q);
+            npiv++;
+        }
+    }
+
+#define VLO(v) ((v) < n ? l[(v)] : 0.0)
+#define VUP(v) ((v) < n ? u[(v)] : INFINITY)
+
+    /* 2. nonbasic sides and basic values */
+    for (int j = 0; j < n; j++) {
+        int v = t.nvar[j];
+        double lo = VLO(v), up = VUP(v);
+        int side;
+        if (lo == up) side = 0;
+        else if (t.d[j] < -MIPX_DTOL) side = isinf(up) ? 2 : 1;
+        else if (t.d[j] > MIPX_DTOL) side = 0;
+        else side = (atup[v] && !isinf(up)) ? 1 : 0;
+        nb_up[j] = (int8_t)side;
+        va[j] = side == 0 ? lo : side == 1 ? up : 0.0;
+        vb[j] = side == 2 ? 1.0 : 0.0;
+    }
+    for (int i = 0; i < m; i++) {
+        const double *Ti = t.T + (size_t)i * n;
+        for (int j = 0; j < n; j++) buf[j] = Ti[j] * va[j];
+        for (int j = n; j < n2; j++) buf[j] = 0.0;
+        ba[i] = t.beta0[i] - fold_sum(buf, n2);
+        for (int j = 0; j < n; j++) buf[j] = Ti[j] * vb[j];
+        for (int j = n; j < n2; j++) buf[j] = 0.0;
+        bb[i] = 0.0 - fold_sum(buf, n2);
+    }
+
+    /* 3. dual simplex */
+    int iters = 0, status = -1;
+    const int cap = 100 * (m + n) + 1000;
+    for (;;) {
+        /* (a) leaving row */
+        int r = -1, rlevel = 0, rvar = 0, sigma = 0; double rviol = 0.0;
+        for (int i = 0; i < m; i++) {
+            int v = t.bvar[i];
+            double lo = VLO(v), up = VUP(v);
+            double a = ba[i], bM = bb[i];
+            int level = 0, sg = 0; double viol = 0.0;
+            if (bM < -MIPX_BTOL) { level = 2; viol = -bM; sg = +1; }
+            else if (bM > MIPX_BTOL) {
+                if (!isinf(up)) { level = 2; viol = bM; sg = -1; }
+                else if (bM > 1.0 + MIPX_BTOL) { level = 2; viol = bM - 1.0; sg = -1; }
+                else if (bM >= 1.0 - MIPX_BTOL && a > MIPX_PTOL) { level = 1; viol = a; sg = -1; }
+            } else {
+                if (a < lo - MIPX_PTOL) { level = 1; viol = lo - a; sg = +1; }
+                else if (!isinf(up) && a > up + MIPX_PTOL) { level = 1; viol = a - up; sg = -1; }
+            }
+            if (level == 0) continue;
+            int better = 0;
+            if (r < 0) better = 1;
+            else if (level != rlevel) better = level > rlevel;
+            else if (viol != rviol) better = viol > rviol;
+            else better = v < rvar;
+            if (better) { r = i; rlevel = level; rviol = viol; rvar = v; sigma = sg; }
+        }
+        if (r < 0) {
+            status = 0;
+            for (int i = 0; i < m; i++) if (bb[i] > MIPX_BTOL) status = 2;
+            for (int j = 0; j < n; j++) if (nb_up[j] == 2) status = 2;
+            break;
+        }
+        if ((max_iter > 0 && iters >= max_iter) || iters >= cap) { status = 3; break; }
+        /* (b) ratio test, Harris two pass */
+        const double *Tr = t.T + (size_t)r * n;
+        double thmax = INFINITY; int jmin = -1, jminvar = 0;
+        for (int j = 0; j < n; j++) {
+            int v = t.nvar[j];
+            if (VLO(v) == VUP(v)) continue;
+            double a = sigma * Tr[j];
+            int elig = nb_up[j] == 0 ? (a < -MIPX_PIVTOL) : (a > MIPX_PIVTOL);
+            if (!elig) continue;
+            double dj = nb_up[j] == 0 ? fmax(t.d[j], 0.0) : fmax(-t.d[j], 0.0);
+            double ratio = (dj + MIPX_DTOL) / fabs(a);
+            if (jmin < 0 || ratio < thmax || (ratio == thmax && v < jminvar)) {
+                thmax = ratio; jmin = j; jminvar = v;
+            }
+        }
+        if (jmin < 0) { status = 1; break; }
+        /* pass 2: largest |a| among columns with dj <= thmax*|a| (the pass-1 argmin always
+         * qualifies); ties -> lowest variable index */
+        int q = -1, qvar = 0; double qabs = 0.0;
+        for (int j = 0; j < n; j++) {
+            int v = t.nvar[j];
+            if (VLO(v) == VUP(v)) continue;
+            double a = sigma * Tr[j];
+            int elig = nb_up[j] == 0 ? (a < -MIPX_PIVTOL) : (a > MIPX_PIVTOL);
+            if (!elig) continue;
+            double dj = nb_up[j] == 0 ? fmax(t.d[j], 0.0) : fmax(-t.d[j], 0.0);
+            double aa = fabs(a);
+            if (j != jmin && dj > thmax * aa) continue;
+            if (q < 0 || aa > qabs || (aa == qabs && v < qvar)) { q = j; qabs = aa; qvar = v; }
+        }
+        /* (c) value update + pivot */
+        {
+            int lv = t.bvar[r];
+            double lo = VLO(lv), up = VUP(lv);
+            double la, lb; int newside;
+            if (sigma > 0) { la = lo; lb = 0.0; newside = 0; }
+            else if (!isinf(up)) { la = up; lb = 0.0; newside = 1; }
+            else { la = 0.0; lb = 1.0; newside = 2; }
+            const double p = Tr[q];
+            const double ta = (ba[r] - la) / p, tb = (bb[r] - lb) / p;
+            for (int i = 0; i < m; i++) {
+                if (i == r) continue;
+                double al = t.T[(size_t)i * n + q];
+                ba[i] = fma(-al, ta, ba[i]);
+                bb[i] = fma(-al, tb, bb[i]);
+            }
+            ba[r] = va[q] + ta;
+            bb[r] = vb[q] + tb;
+            tab_pivot(&t, r, q);
+            nb_up[q] = (int8_t)newside;
+            va[q] = la; vb[q] = lb;
+            iters++; npiv++;
+        }
+    }
+
+    /* 4. outputs */
+    if (x_out || obj_out) {
+        double *x = (double *)malloc(sizeof(double) * (size_t)n);
+        for (int j = 0; j < n; j++) {
+            int v = t.nvar[j];
+            if (v < n) x[v] = nb_up[j] == 2 ? INFINITY : va[j];
+        }
+        for (int i = 0; i < m; i++) {
+            int v = t.bvar[i];
+            if (v < n) x[v] = ba[i];
+        }
+        if (obj_out) {
+            if (status == 1) *obj_out = INFINITY;
+            else if (status == 2) *obj_out = -INFINITY;
+            else {
+                for (int j = 0; j < n; j++) buf[j] = c[j] * x[j];
+                for (int j = n; j < n2; j++) buf[j] = 0.0;
+                *obj_out = fold_sum(buf, n2);
+            }
+        }
+        if (x_out) memcpy(x_out, x, sizeof(double) * (size_t)n);
+        free(x);
+    }
+    if (y_out) {
+        for (int i = 0; i < m; i++) y_out[i] = 0.0;
+        for (int j = 0; j < n; j++) if (t.nvar[j] >= n) y_out[t.nvar[j] - n] = t.d[j];
+    }
+    if (dj_out) {
+        for (int j = 0; j < n; j++) dj_out[j] = 0.0;
+        for (int j = 0; j < n; j++) if (t.nvar[j] < n) dj_out[t.nvar[j]] = t.d[j];
+    }
+    if (vstat_out) {
+        for (int i = 0; i < m; i++) vstat_out[t.bvar[i]] = ST_BASIC;
+        for (int j = 0; j < n; j++) vstat_out[t.nvar[j]] = nb_up[j] ? ST_UPPER : ST_LOWER;
+    }
+    if (status_out) *status_out = status;
+    if (iters_out) *iters_out = iters;
+    if (npivots_out) *npivots_out = npiv;
+
+    free(t.T); free(t.beta0); free(t.d); free(t.bvar); free(t.nvar);
+    free(atup); free(wantb); free(nb_up); free(ba); free(bb); free(buf); free(va); free(vb);
+    return 0;
+}
+
+/* batch of node LPs sharing (A,b,c): l,u are batch x n, vstat batch x (n+m) (or NULL) */
+int mipx_oracle_lp_solve_batch(int m, int n, const double *A, const double *b, const double *c,
+                               int batch, const double *l, const double *u,
+                               const int8_t *vstat_in, int max_iter, int32_t *status, double *obj,
+                               double *x, double *y, int8_t *vstat_out, int32_t *iters,
+                               int32_t *npivots) {
+    for (int k = 0; k < batch; k++) {
+        int rc = mipx_oracle_lp_solve(
+            m, n, A, b, c, l + (size_t)k * n, u + (size_t)k * n,
+            vstat_in ? vstat_in + (size_t)k * (n + m) : NULL, max_iter, status ? status + k : NULL,
+            obj ? obj + k : NULL, x ? x + (size_t)k * n : NULL, y ? y + (size_t)k * m : NULL, NULL,
+            vstat_out ? vstat_out + (size_t)k * (n + m) : NULL, iters ? iters + k : NULL,
+            npivots ? npivots + k : NULL);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Branching: base_node.py:544-562 (_most_fractional_index), :649-666
+ * ---------------------------------------------------------------------------------------- */
+#define VARIABLE_EPSILON 1e-4 /* utils/tolerance.py:2 */
+
+/* returns index of most fractional integer variable or -1 (reference: None) */
+int mipx_oracle_most_fractional(int n_int, const int32_t *int_idx, const double *x) {
+    int furthest = -1; double fd = VARIABLE_EPSILON;
+    for (int k = 0; k < n_int; k++) {
+        double v = x[int_idx[k]];
+        double dist = fmin(v - floor(v), ceil(v) - v);
+        if (dist > fd) { fd = dist; furthest = int_idx[k]; }
+    }
+    return furthest;
+}
+
+/* mip_feasible test of base_node.py:281-283 */
+int mipx_oracle_mip_feasible(int n_int, const int32_t *int_idx, const double *x) {
+    double worst = 0.0;
+    for (int k = 0; k < n_int; k++) {
+        double v = x[int_idx[k]];
+        double e = fabs(rint(v) - v); /* np.round = half-to-even = rint in default mode */
+        if (e > worst) worst = e;
+    }
+    return worst <= VARIABLE_EPSILON;
+}
+
+/*
+ * pseudo_cost.py:118-133: score_i = min(cost_right*(ceil-x), cost_left*(x-floor)) over fractional
+ * integer i; argmax with ties -> earliest in int_idx order (stable descending sort).
+ * cost arrays are indexed by variable (length n); returns -1 if no fractional variable.
+ */
+int mipx_oracle_best_pseudo_cost(int n_int, const int32_t *int_idx, const double *x,
+                                 const double *cost_left, const double *cost_right) {
+    int best = -1; double bs = 0.0;
+    for (int k = 0; k < n_int; k++) {
+        int i = int_idx[k];
+        double v = x[i];
+        double fl = floor(v), ce = ceil(v);
+        if (!(fmin(v - fl, ce - v) > VARIABLE_EPSILON)) continue;
+        double s = fmin(cost_right[i] * (ce - v), cost_left[i] * (v - fl));
+        if (best < 0 || s > bs) { best = i; bs = s; }
+    }
+    return best;
+}
+
+/* pseudo_cost.py:68-100 running mean update; status = LP status of the (probe or own) node */
+void mipx_oracle_pseudo_cost_update(double *cost, int32_t *times, int status, double objective,
+                                    double dual_bound, double variable_change) {
+    if (status == 0 || status == 3) {
+        double bc = objective - dual_bound;
+        if (bc < 0) bc = 0;
+        *cost = (*cost * (double)*times + bc / variable_change) / (double)(*times + 1);
+    }
+    *times += 1;
+}

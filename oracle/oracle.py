@@ -1,0 +1,108 @@
+"""ctypes wrapper around oracle/libmipx_oracle.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+See the header of mipx_oracle.c for what it restates (reference file:line) and its parity status.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_dp = C.POINTER(C.c_double)
+_i8p = C.POINTER(C.c_int8)
+_i32p = C.POINTER(C.c_int32)
+
+
+def build():
+    subprocess.check_call(['make', '-C', _HERE, '-s'])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, 'libmipx_oracle.so')
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.mipx_oracle_lp_solve_batch.restype = C.c_int
+        _LIB.mipx_oracle_most_fractional.restype = C.c_int
+        _LIB.mipx_oracle_mip_feasible.restype = C.c_int
+        _LIB.mipx_oracle_best_pseudo_cost.restype = C.c_int
+        _LIB.mipx_oracle_pseudo_cost_update.restype = None
+    return _LIB
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def lp_solve_batch(A, b, c, l, u, vstat=None, max_iter=0):
+    """Solve a batch of node LPs  min c'x, Ax >= b, l_k <= x <= u_k  sharing (A, b, c).
+
+    l, u: (batch, n); vstat: (batch, n+m) int8 Clp status codes or None (cold start).
+    Returns dict(status, obj, x, y, vstat, iters, npivots).
+    """
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    m, n = A.shape
+    b = np.ascontiguousarray(b, dtype=np.float64).reshape(m)
+    c = np.ascontiguousarray(c, dtype=np.float64).reshape(n)
+    l = np.ascontiguousarray(l, dtype=np.float64).reshape(-1, n)
+    u = np.ascontiguousarray(u, dtype=np.float64).reshape(-1, n)
+    batch = l.shape[0]
+    if vstat is not None:
+        vstat = np.ascontiguousarray(vstat, dtype=np.int8).reshape(batch, n + m)
+    status = np.zeros(batch, np.int32)
+    obj = np.zeros(batch, np.float64)
+    x = np.zeros((batch, n), np.float64)
+    y = np.zeros((batch, m), np.float64)
+    vout = np.zeros((batch, n + m), np.int8)
+    iters = np.zeros(batch, np.int32)
+    npiv = np.zeros(batch, np.int32)
+    rc = lib().mipx_oracle_lp_solve_batch(
+        C.c_int(m), C.c_int(n), _p(A, _dp), _p(b, _dp), _p(c, _dp), C.c_int(batch), _p(l, _dp),
+        _p(u, _dp), _p(vstat, _i8p), C.c_int(int(max_iter)), _p(status, _i32p), _p(obj, _dp),
+        _p(x, _dp), _p(y, _dp), _p(vout, _i8p), _p(iters, _i32p), _p(npiv, _i32p))
+    assert rc == 0, f'oracle lp_solve_batch failed rc={rc}'
+    return dict(status=status, obj=obj, x=x, y=y, vstat=vout, iters=iters, npivots=npiv)
+
+
+def lp_solve(A, b, c, l, u, vstat=None, max_iter=0):
+    r = lp_solve_batch(A, b, c, np.asarray(l, float)[None], np.asarray(u, float)[None],
+                       None if vstat is None else np.asarray(vstat, np.int8)[None], max_iter)
+    return {k: v[0] for k, v in r.items()}
+
+
+def most_fractional(int_idx, x):
+    ii = np.ascontiguousarray(int_idx, np.int32)
+    x = np.ascontiguousarray(x, np.float64)
+    r = lib().mipx_oracle_most_fractional(C.c_int(len(ii)), _p(ii, _i32p), _p(x, _dp))
+    return None if r < 0 else int(r)
+
+
+def mip_feasible(int_idx, x):
+    ii = np.ascontiguousarray(int_idx, np.int32)
+    x = np.ascontiguousarray(x, np.float64)
+    return bool(lib().mipx_oracle_mip_feasible(C.c_int(len(ii)), _p(ii, _i32p), _p(x, _dp)))
+
+
+def best_pseudo_cost(int_idx, x, cost_left, cost_right):
+    ii = np.ascontiguousarray(int_idx, np.int32)
+    x = np.ascontiguousarray(x, np.float64)
+    cl = np.ascontiguousarray(cost_left, np.float64)
+    cr = np.ascontiguousarray(cost_right, np.float64)
+    r = lib().mipx_oracle_best_pseudo_cost(C.c_int(len(ii)), _p(ii, _i32p), _p(x, _dp),
+                                           _p(cl, _dp), _p(cr, _dp))
+    return None if r < 0 else int(r)
+
+
+def pseudo_cost_update(cost, times, status, objective, dual_bound, variable_change):
+    cc = C.c_double(cost)
+    tt = C.c_int32(times)
+    lib().mipx_oracle_pseudo_cost_update(C.byref(cc), C.byref(tt), C.c_int(status),
+                                         C.c_double(objective), C.c_double(dual_bound),
+                                         C.c_double(variable_change))
+    return cc.value, tt.value

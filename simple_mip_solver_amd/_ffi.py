@@ -1,0 +1,217 @@
+"""ctypes binding of libmipx.so (include/mipx.h).  Fails loudly: there is no CPU fallback.
+
+The library is built in-tree by `make -C simple_mip_solver_amd/csrc` (see __graft_entry__.build).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmipx.so')
+
+MIPX_OK = 0
+ERRORS = {-1: 'MIPX_EINVAL', -2: 'MIPX_ENODEV', -3: 'MIPX_EHIP', -4: 'MIPX_ETOOBIG',
+          -5: 'MIPX_ENOMEM'}
+
+# every symbol include/mipx.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    'mipx_abi_version', 'mipx_device_count', 'mipx_ctx_create', 'mipx_ctx_destroy',
+    'mipx_last_error', 'mipx_ctx_sync', 'mipx_problem_create', 'mipx_problem_destroy',
+    'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_dev_alloc', 'mipx_dev_free',
+    'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
+    'mipx_kernel_name',
+]
+
+_dp = C.POINTER(C.c_double)
+_i8p = C.POINTER(C.c_int8)
+_i32p = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+_lib = None
+
+
+class MipxError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmipx.so; raise MipxError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MipxError(
+            f'{LIB_PATH} is missing: the HIP extension has not been built '
+            f'(run `make -C {os.path.dirname(LIB_PATH)}` or __graft_entry__.build()). '
+            'simple_mip_solver_amd has no CPU fallback.')
+    L = C.CDLL(LIB_PATH)
+    L.mipx_abi_version.restype = C.c_int
+    L.mipx_device_count.restype = C.c_int
+    L.mipx_ctx_create.argtypes = [C.c_int, C.POINTER(_vp)]
+    L.mipx_ctx_destroy.argtypes = [_vp]
+    L.mipx_ctx_destroy.restype = None
+    L.mipx_last_error.argtypes = [_vp]
+    L.mipx_last_error.restype = C.c_char_p
+    L.mipx_ctx_sync.argtypes = [_vp]
+    L.mipx_problem_create.argtypes = [_vp, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(_vp)]
+    L.mipx_problem_destroy.argtypes = [_vp]
+    L.mipx_problem_destroy.restype = None
+    solve_args = [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.mipx_lp_solve_batch.argtypes = solve_args
+    L.mipx_lp_solve_batch_dev.argtypes = solve_args
+    L.mipx_dev_alloc.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
+    L.mipx_dev_free.argtypes = [_vp, _vp]
+    L.mipx_memcpy_h2d.argtypes = [_vp, _vp, _vp, C.c_size_t]
+    L.mipx_memcpy_d2h.argtypes = [_vp, _vp, _vp, C.c_size_t]
+    L.mipx_timer_start.argtypes = [_vp]
+    L.mipx_timer_stop.argtypes = [_vp, C.POINTER(C.c_float)]
+    L.mipx_kernel_name.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+class Context:
+    """One GPU + one HIP stream (mipx_ctx)."""
+
+    def __init__(self, device=0):
+        L = lib()
+        h = _vp()
+        rc = L.mipx_ctx_create(int(device), C.byref(h))
+        if rc != MIPX_OK:
+            raise MipxError(
+                f'mipx_ctx_create(device={device}) failed: {ERRORS.get(rc, rc)} '
+                f'({L.mipx_device_count()} HIP devices visible). '
+                'simple_mip_solver_amd needs an MI355X (gfx950); there is no CPU fallback.')
+        self._h = h
+        self.device = device
+
+    def check(self, rc, what):
+        if rc != MIPX_OK:
+            msg = lib().mipx_last_error(self._h)
+            raise MipxError(f'{what} failed: {ERRORS.get(rc, rc)}: '
+                            f'{msg.decode() if msg else ""}')
+
+    def sync(self):
+        self.check(lib().mipx_ctx_sync(self._h), 'mipx_ctx_sync')
+
+    def timer_start(self):
+        self.check(lib().mipx_timer_start(self._h), 'mipx_timer_start')
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self.check(lib().mipx_timer_stop(self._h, C.byref(ms)), 'mipx_timer_stop')
+        return ms.value
+
+    def alloc(self, nbytes):
+        d = _vp()
+        self.check(lib().mipx_dev_alloc(self._h, nbytes, C.byref(d)), 'mipx_dev_alloc')
+        return d
+
+    def free(self, d):
+        self.check(lib().mipx_dev_free(self._h, d), 'mipx_dev_free')
+
+    def h2d(self, d, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(lib().mipx_memcpy_h2d(self._h, d, _ptr(arr), arr.nbytes), 'mipx_memcpy_h2d')
+
+    def d2h(self, arr, d):
+        assert arr.flags['C_CONTIGUOUS']
+        self.check(lib().mipx_memcpy_d2h(self._h, _ptr(arr), d, arr.nbytes), 'mipx_memcpy_d2h')
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        d = self.alloc(arr.nbytes)
+        self.h2d(d, arr)
+        return d
+
+    def close(self):
+        if getattr(self, '_h', None):
+            lib().mipx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Problem:
+    """(A, b, c) of one tree resident in HBM (mipx_problem)."""
+
+    def __init__(self, ctx, A, b, c):
+        self.ctx = ctx
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        if A.ndim != 2:
+            A = A.reshape(-1, len(c))
+        self.m, self.n = A.shape
+        b = np.ascontiguousarray(b, dtype=np.float64).reshape(self.m)
+        c = np.ascontiguousarray(c, dtype=np.float64).reshape(self.n)
+        h = _vp()
+        rc = lib().mipx_problem_create(ctx._h, self.m, self.n, A.ctypes.data_as(_dp),
+                                       b.ctypes.data_as(_dp), c.ctypes.data_as(_dp), C.byref(h))
+        ctx.check(rc, f'mipx_problem_create(m={self.m}, n={self.n})')
+        self._h = h
+
+    def solve_batch(self, l, u, vstat=None, max_iter=0):
+        """Host-buffer batched LP relaxation; returns dict like the oracle's."""
+        n, m = self.n, self.m
+        l = np.ascontiguousarray(l, dtype=np.float64).reshape(-1, n)
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(-1, n)
+        B = l.shape[0]
+        assert u.shape[0] == B
+        if vstat is not None:
+            vstat = np.ascontiguousarray(vstat, dtype=np.int8).reshape(B, n + m)
+        status = np.zeros(B, np.int32)
+        obj = np.zeros(B, np.float64)
+        x = np.zeros((B, n), np.float64)
+        y = np.zeros((B, m), np.float64)
+        vout = np.zeros((B, n + m), np.int8)
+        iters = np.zeros(B, np.int32)
+        npiv = np.zeros(B, np.int32)
+        rc = lib().mipx_lp_solve_batch(self._h, B, _ptr(l), _ptr(u), _ptr(vstat), int(max_iter),
+                                       _ptr(status), _ptr(obj), _ptr(x), _ptr(y), _ptr(vout),
+                                       _ptr(iters), _ptr(npiv))
+        self.ctx.check(rc, 'mipx_lp_solve_batch')
+        return dict(status=status, obj=obj, x=x, y=y, vstat=vout, iters=iters, npivots=npiv)
+
+    def solve_batch_dev(self, B, d_l, d_u, d_vstat, max_iter, d_status, d_obj, d_x, d_y, d_vout,
+                        d_iters, d_npiv):
+        rc = lib().mipx_lp_solve_batch_dev(self._h, int(B), d_l, d_u, d_vstat, int(max_iter),
+                                           d_status, d_obj, d_x, d_y, d_vout, d_iters, d_npiv)
+        self.ctx.check(rc, 'mipx_lp_solve_batch_dev')
+
+    def close(self):
+        if getattr(self, '_h', None) and getattr(self.ctx, '_h', None):
+            lib().mipx_problem_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def kernel_name(m, n):
+    buf = C.create_string_buffer(128)
+    rc = lib().mipx_kernel_name(int(m), int(n), buf, 128)
+    if rc != MIPX_OK:
+        raise MipxError(f'no on-chip kernel for m={m}, n={n}: {ERRORS.get(rc, rc)}')
+    return buf.value.decode()
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on the GPU selected by LOCAL_RANK (one process per GPU)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get('LOCAL_RANK', '0')))
+    return _default_ctx

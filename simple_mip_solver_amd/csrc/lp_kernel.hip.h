@@ -1,0 +1,520 @@
+// lp_kernel.hip.h -- K1: batched bounded dual simplex, one workgroup per node LP, gfx950.
+//
+// Replaces what the reference asks Clp to do in BaseNode._bound_lp / _strong_branch
+// (simple_mip_solver/nodes/base_node.py:273, :645-646).  Not a translation of anything: the
+// reference has no kernel.  Design:
+//
+//   * The condensed simplex tableau T (m x n, f64) lives in VGPRs for the whole solve: thread
+//     (bi, bj) of a TBI x TBJ thread grid owns T[bi + TBI*ii][bj + TBJ*jj], ii < R, jj < C.
+//     256x128 -> 16x32 threads x 8x8 doubles = 256 KiB of registers on one CU; it never touches
+//     HBM again after the initial coalesced read of A.
+//   * The interleaved ownership makes every LDS access of the per-pivot vectors (pivot row rho,
+//     pivot column alpha) conflict-free (consecutive lanes -> consecutive 8-byte words, or a
+//     half-wave broadcast), and lets work scale with ceil(m/TBI), ceil(n/TBJ).
+//   * Borders (beta0, reduced costs d, basic values a + b*M, bounds, basis lists) live in LDS.
+//   * Row/column extraction uses wave-uniform (SGPR) local indices so register arrays are only
+//     ever indexed statically (no scratch).
+//   * Selections (leaving row, Harris ratio test) are wavefront-wide butterfly reductions done
+//     redundantly by every wave, so they need no extra barrier to publish the winner.
+//   * Arithmetic is IEEE f64 with explicit fma and true division, compiled with
+//     -ffp-contract=off, following the canonical operation order documented in
+//     oracle/mipx_oracle.c so results are bit-identical to the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mipx {
+
+constexpr double kPTol = 1e-7;
+constexpr double kDTol = 1e-7;
+constexpr double kPivTol = 1e-9;
+constexpr double kBTol = 1e-9;
+
+struct LpArgs {
+    int m, n;
+    const double *A, *b, *c;       // shared by the batch
+    const double *l, *u;           // batch x n
+    const int8_t *vstat_in;        // batch x (n+m) or nullptr
+    int max_iter;
+    int32_t *status;
+    double *obj;
+    double *x;                     // batch x n
+    double *y;                     // batch x m
+    int8_t *vstat_out;             // batch x (n+m)
+    int32_t *iters;
+    int32_t *npivots;
+    int batch;
+};
+
+struct Best {
+    int hi;      // maximise
+    double key;  // then maximise
+    int lo;      // then minimise
+    int idx;     // payload
+};
+
+__device__ __forceinline__ bool better(const Best &a, const Best &b) {
+    if (a.hi != b.hi) return a.hi > b.hi;
+    if (a.key != b.key) return a.key > b.key;
+    return a.lo < b.lo;
+}
+
+__device__ __forceinline__ Best wave_best(Best v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Best o;
+        o.hi = __shfl_xor(v.hi, off);
+        o.key = __shfl_xor(v.key, off);
+        o.lo = __shfl_xor(v.lo, off);
+        o.idx = __shfl_xor(v.idx, off);
+        if (better(o, v)) v = o;
+    }
+    return v;
+}
+
+template <int MP, int NP>
+struct Smem {
+    double row[NP];    // extracted pivot row
+    double rho[NP];    // row / p
+    double alpha[MP];  // extracted pivot column
+    double coln[MP];   // -alpha / p
+    double beta0[MP];
+    double ba[MP];
+    double bb[MP];
+    double d[NP];
+    double va[NP];
+    double vb[NP];
+    double lo[NP];     // structural bounds by variable index
+    double up[NP];
+    double key[NP];    // scratch: ratio keys / x assembly
+    double aabs[NP];
+    double dje[NP];
+    double scal[16];
+    int bvar[MP];
+    int nvar[NP];
+    int side[NP];      // 0 lower, 1 upper, 2 fake upper
+    int8_t wantb[NP + MP];
+    int8_t atup[NP + MP];
+};
+
+enum { S_RHON = 0, S_TA, S_TB, S_NBA, S_NBB, S_DQ, S_DQN, S_PINV, S_LA, S_LB };
+
+template <int TBI, int TBJ, int R, int C>
+__global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
+    constexpr int NT = TBI * TBJ;
+    constexpr int MP = TBI * R;
+    constexpr int NP = TBJ * C;
+    static_assert((NP & (NP - 1)) == 0, "padded column count must be a power of two");
+    static_assert(NT % 64 == 0, "whole waves only");
+    __shared__ Smem<MP, NP> s;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int bi = tid / TBJ;
+    const int bj = tid % TBJ;
+    const int m = g.m, n = g.n;
+    const int nv = n + m;
+    const double INF = __builtin_huge_val();
+
+    for (int node = blockIdx.x; node < g.batch; node += gridDim.x) {
+        double T[R][C];
+        const double *lk = g.l + (size_t)node * n;
+        const double *uk = g.u + (size_t)node * n;
+        const int8_t *vin = g.vstat_in ? g.vstat_in + (size_t)node * nv : nullptr;
+
+        // ---- 0. T = -A, beta0 = -b, d = c, slack basis -------------------------------------
+#pragma unroll
+        for (int ii = 0; ii < R; ii++) {
+            const int i = bi + TBI * ii;
+#pragma unroll
+            for (int jj = 0; jj < C; jj++) {
+                const int j = bj + TBJ * jj;
+                T[ii][jj] = (i < m && j < n) ? -g.A[(size_t)i * n + j] : 0.0;
+            }
+        }
+        for (int i = tid; i < MP; i += NT) {
+            s.beta0[i] = i < m ? -g.b[i] : 0.0;
+            s.bvar[i] = i < m ? n + i : -1;
+            s.ba[i] = 0.0;
+            s.bb[i] = 0.0;
+        }
+        for (int j = tid; j < NP; j += NT) {
+            s.d[j] = j < n ? g.c[j] : 0.0;
+            s.nvar[j] = j < n ? j : -1;
+            s.lo[j] = j < n ? lk[j] : 0.0;
+            s.up[j] = j < n ? uk[j] : 0.0;
+            s.side[j] = 0;
+            s.va[j] = 0.0;
+            s.vb[j] = 0.0;
+        }
+        for (int v = tid; v < NP + MP; v += NT) {
+            int8_t st = (vin && v < nv) ? vin[v] : (int8_t)0;
+            s.wantb[v] = st == 1;
+            s.atup[v] = st == 2;
+        }
+        __syncthreads();
+
+        auto vlo = [&](int v) -> double { return v < n ? s.lo[v] : 0.0; };
+        auto vup = [&](int v) -> double { return v < n ? s.up[v] : INF; };
+
+        auto extract_col = [&](int q) {  // s.alpha[i] = T[i][q]
+            const int qb = q % TBJ, ql = q / TBJ;
+            if (bj == qb) {
+#pragma unroll
+                for (int jj = 0; jj < C; jj++) {
+                    if (jj == ql) {
+#pragma unroll
+                        for (int ii = 0; ii < R; ii++) s.alpha[bi + TBI * ii] = T[ii][jj];
+                    }
+                }
+            }
+        };
+        auto extract_row = [&](int r) {  // s.row[j] = T[r][j]
+            const int rb = r % TBI, rl = r / TBI;
+            if (bi == rb) {
+#pragma unroll
+                for (int ii = 0; ii < R; ii++) {
+                    if (ii == rl) {
+#pragma unroll
+                        for (int jj = 0; jj < C; jj++) s.row[bj + TBJ * jj] = T[ii][jj];
+                    }
+                }
+            }
+        };
+        // rank-1 update of the register tableau + borders, given s.alpha, s.rho, s.coln, s.scal
+        auto apply_pivot = [&](int r, int q, bool with_values, int newside) {
+            const int rb = r % TBI, rl = r / TBI;
+            const int qb = q % TBJ, ql = q / TBJ;
+            double al[R], rh[C];
+#pragma unroll
+            for (int ii = 0; ii < R; ii++) al[ii] = s.alpha[bi + TBI * ii];
+#pragma unroll
+            for (int jj = 0; jj < C; jj++) rh[jj] = s.rho[bj + TBJ * jj];
+#pragma unroll
+            for (int ii = 0; ii < R; ii++) {
+                const double a = (bi == rb && ii == rl) ? 0.0 : al[ii];
+#pragma unroll
+                for (int jj = 0; jj < C; jj++) {
+                    const double h = (bj == qb && jj == ql) ? 0.0 : rh[jj];
+                    T[ii][jj] = fma(-a, h, T[ii][jj]);
+                }
+            }
+            // column q <- -alpha/p (rows != r)
+            if (bj == qb) {
+#pragma unroll
+                for (int jj = 0; jj < C; jj++) {
+                    if (jj == ql) {
+#pragma unroll
+                        for (int ii = 0; ii < R; ii++) T[ii][jj] = s.coln[bi + TBI * ii];
+                    }
+                }
+            }
+            // row r <- rho (and 1/p at column q)
+            if (bi == rb) {
+                const double pinv = s.scal[S_PINV];
+#pragma unroll
+                for (int ii = 0; ii < R; ii++) {
+                    if (ii == rl) {
+#pragma unroll
+                        for (int jj = 0; jj < C; jj++)
+                            T[ii][jj] = (bj == qb && jj == ql) ? pinv : rh[jj];
+                    }
+                }
+            }
+            // borders
+            const double rhon = s.scal[S_RHON];
+            const double ta = s.scal[S_TA], tb = s.scal[S_TB];
+            for (int i = tid; i < m; i += NT) {
+                const double a = s.alpha[i];
+                if (i == r) {
+                    s.beta0[i] = rhon;
+                    if (with_values) { s.ba[i] = s.scal[S_NBA]; s.bb[i] = s.scal[S_NBB]; }
+                } else {
+                    s.beta0[i] = fma(-a, rhon, s.beta0[i]);
+                    if (with_values) {
+                        s.ba[i] = fma(-a, ta, s.ba[i]);
+                        s.bb[i] = fma(-a, tb, s.bb[i]);
+                    }
+                }
+            }
+            const double dq = s.scal[S_DQ];
+            for (int j = tid; j < n; j += NT) {
+                if (j == q) {
+                    s.d[j] = s.scal[S_DQN];
+                    if (with_values) {
+                        s.side[j] = newside;
+                        s.va[j] = s.scal[S_LA];
+                        s.vb[j] = s.scal[S_LB];
+                    }
+                } else {
+                    s.d[j] = fma(-dq, s.rho[j], s.d[j]);
+                }
+            }
+            if (tid == NT - 1) {
+                const int tmp = s.bvar[r];
+                s.bvar[r] = s.nvar[q];
+                s.nvar[q] = tmp;
+            }
+        };
+        // rho, coln and scalar pieces from s.row / s.alpha (row r and column q extracted)
+        auto prepare_pivot = [&](int r, int q, bool with_values, double la, double lb) {
+            const double p = s.row[q];
+            for (int k = tid; k < n + m; k += NT) {
+                if (k < n) s.rho[k] = s.row[k] / p;
+                else s.coln[k - n] = -s.alpha[k - n] / p;
+            }
+            if (tid == NT - 1) {
+                s.scal[S_PINV] = 1.0 / p;
+                s.scal[S_RHON] = s.beta0[r] / p;
+                const double dq = s.d[q];
+                s.scal[S_DQ] = dq;
+                s.scal[S_DQN] = -dq / p;
+                if (with_values) {
+                    const double ta = (s.ba[r] - la) / p, tb = (s.bb[r] - lb) / p;
+                    s.scal[S_TA] = ta;
+                    s.scal[S_TB] = tb;
+                    s.scal[S_NBA] = s.va[q] + ta;
+                    s.scal[S_NBB] = s.vb[q] + tb;
+                    s.scal[S_LA] = la;
+                    s.scal[S_LB] = lb;
+                }
+            }
+        };
+
+        int npiv = 0;
+
+        // ---- 1. refactor to the warm-start basis -------------------------------------------
+        if (vin) {
+            for (int q = 0; q < n; q++) {
+                if (!__builtin_amdgcn_readfirstlane((int)s.wantb[q])) continue;  // uniform
+                extract_col(q);
+                __syncthreads();
+                Best best{-1, 0.0, 0, -1}, fb{-1, 0.0, 0, -1};
+                for (int i = lane; i < m; i += 64) {
+                    const int bv = s.bvar[i];
+                    if (bv < n) continue;
+                    const double a = fabs(s.alpha[i]);
+                    if (!(a > kPivTol)) continue;
+                    Best cand{0, a, i, i};
+                    if (better(cand, fb)) fb = cand;
+                    if (!s.wantb[bv] && better(cand, best)) best = cand;
+                }
+                best = wave_best(best);
+                if (__builtin_amdgcn_readfirstlane(best.hi) < 0) best = wave_best(fb);
+                const int r = __builtin_amdgcn_readfirstlane(best.idx);
+                if (r < 0) { __syncthreads(); continue; }
+                extract_row(r);
+                __syncthreads();
+                prepare_pivot(r, q, false, 0.0, 0.0);
+                __syncthreads();
+                apply_pivot(r, q, false, 0);
+                __syncthreads();
+                npiv++;
+            }
+        }
+
+        // ---- 2. nonbasic sides, basic values ------------------------------------------------
+        for (int j = tid; j < n; j += NT) {
+            const int v = s.nvar[j];
+            const double lo = vlo(v), up = vup(v);
+            const double dj = s.d[j];
+            int side;
+            if (lo == up) side = 0;
+            else if (dj < -kDTol) side = isinf(up) ? 2 : 1;
+            else if (dj > kDTol) side = 0;
+            else side = (s.atup[v] && !isinf(up)) ? 1 : 0;
+            s.side[j] = side;
+            s.va[j] = side == 0 ? lo : side == 1 ? up : 0.0;
+            s.vb[j] = side == 2 ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        {
+            double va[C], vb[C];
+#pragma unroll
+            for (int jj = 0; jj < C; jj++) {
+                va[jj] = s.va[bj + TBJ * jj];
+                vb[jj] = s.vb[bj + TBJ * jj];
+            }
+#pragma unroll
+            for (int ii = 0; ii < R; ii++) {
+                double pa[C], pb[C];
+#pragma unroll
+                for (int jj = 0; jj < C; jj++) {
+                    pa[jj] = T[ii][jj] * va[jj];
+                    pb[jj] = T[ii][jj] * vb[jj];
+                }
+#pragma unroll
+                for (int h = C / 2; h >= 1; h >>= 1) {
+#pragma unroll
+                    for (int jj = 0; jj < h; jj++) {
+                        pa[jj] = pa[jj] + pa[jj + h];
+                        pb[jj] = pb[jj] + pb[jj + h];
+                    }
+                }
+                double sa = pa[0], sb = pb[0];
+#pragma unroll
+                for (int h = TBJ / 2; h >= 1; h >>= 1) {
+                    sa = sa + __shfl_down(sa, h, TBJ);
+                    sb = sb + __shfl_down(sb, h, TBJ);
+                }
+                const int i = bi + TBI * ii;
+                if (bj == 0 && i < m) {
+                    s.ba[i] = s.beta0[i] - sa;
+                    s.bb[i] = 0.0 - sb;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- 3. dual simplex ---------------------------------------------------------------
+        int iters = 0, status = -1;
+        const int cap = 100 * (m + n) + 1000;
+        for (;;) {
+            // (a) leaving row: every wave reduces redundantly
+            Best best{-1, 0.0, 0, -1};
+            for (int i = lane; i < m; i += 64) {
+                const int v = s.bvar[i];
+                const double lo = vlo(v), up = vup(v);
+                const double a = s.ba[i], bM = s.bb[i];
+                int level = 0, sg = 0;
+                double viol = 0.0;
+                if (bM < -kBTol) { level = 2; viol = -bM; sg = 1; }
+                else if (bM > kBTol) {
+                    if (!isinf(up)) { level = 2; viol = bM; sg = -1; }
+                    else if (bM > 1.0 + kBTol) { level = 2; viol = bM - 1.0; sg = -1; }
+                    else if (bM >= 1.0 - kBTol && a > kPTol) { level = 1; viol = a; sg = -1; }
+                } else {
+                    if (a < lo - kPTol) { level = 1; viol = lo - a; sg = 1; }
+                    else if (!isinf(up) && a > up + kPTol) { level = 1; viol = a - up; sg = -1; }
+                }
+                if (level == 0) continue;
+                Best cand{level, viol, v, sg > 0 ? i : (i | (1 << 30))};
+                if (better(cand, best)) best = cand;
+            }
+            best = wave_best(best);
+            if (__builtin_amdgcn_readfirstlane(best.hi) < 0) {
+                int bad = 0;
+                for (int i = lane; i < m; i += 64) bad |= s.bb[i] > kBTol;
+                for (int j = lane; j < n; j += 64) bad |= s.side[j] == 2;
+                status = __any(bad) ? 2 : 0;
+                break;
+            }
+            if ((g.max_iter > 0 && iters >= g.max_iter) || iters >= cap) { status = 3; break; }
+            const int ridx = __builtin_amdgcn_readfirstlane(best.idx);
+            const int r = ridx & ~(1 << 30);
+            const int sigma = (ridx & (1 << 30)) ? -1 : 1;
+
+            // (b) pivot row to LDS
+            extract_row(r);
+            __syncthreads();
+
+            // (c) Harris ratio test
+            for (int j = tid; j < n; j += NT) {
+                const int v = s.nvar[j];
+                const double a = sigma * s.row[j];
+                const int sd = s.side[j];
+                bool elig = vlo(v) != vup(v) && (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
+                const double dj = sd == 0 ? fmax(s.d[j], 0.0) : fmax(-s.d[j], 0.0);
+                const double aa = fabs(a);
+                s.key[j] = elig ? (dj + kDTol) / aa : INF;
+                s.aabs[j] = elig ? aa : -1.0;
+                s.dje[j] = dj;
+            }
+            __syncthreads();
+            Best mn{-1, 0.0, 0, -1};
+            for (int j = lane; j < n; j += 64) {
+                if (s.aabs[j] < 0.0) continue;
+                Best cand{0, -s.key[j], s.nvar[j], j};
+                if (better(cand, mn)) mn = cand;
+            }
+            mn = wave_best(mn);
+            if (__builtin_amdgcn_readfirstlane(mn.hi) < 0) { status = 1; break; }
+            const double thmax = -mn.key;
+            const int jmin = __builtin_amdgcn_readfirstlane(mn.idx);
+            Best bq{-1, 0.0, 0, -1};
+            for (int j = lane; j < n; j += 64) {
+                const double aa = s.aabs[j];
+                if (aa < 0.0) continue;
+                if (j != jmin && s.dje[j] > thmax * aa) continue;
+                Best cand{0, aa, s.nvar[j], j};
+                if (better(cand, bq)) bq = cand;
+            }
+            bq = wave_best(bq);
+            const int q = __builtin_amdgcn_readfirstlane(bq.idx);
+
+            // (d) pivot column to LDS, leaving-variable target
+            extract_col(q);
+            const int lv = s.bvar[r];
+            double la, lb;
+            int newside;
+            {
+                const double lo = vlo(lv), up = vup(lv);
+                if (sigma > 0) { la = lo; lb = 0.0; newside = 0; }
+                else if (!isinf(up)) { la = up; lb = 0.0; newside = 1; }
+                else { la = 0.0; lb = 1.0; newside = 2; }
+            }
+            __syncthreads();
+            // (e) rho, coln, scalars
+            prepare_pivot(r, q, true, la, lb);
+            __syncthreads();
+            // (f) update
+            apply_pivot(r, q, true, newside);
+            __syncthreads();
+            iters++;
+            npiv++;
+        }
+
+        // ---- 4. outputs --------------------------------------------------------------------
+        // assemble x by variable index in s.key
+        for (int j = tid; j < n; j += NT) {
+            const int v = s.nvar[j];
+            if (v < n) s.key[v] = s.side[j] == 2 ? INF : s.va[j];
+        }
+        for (int i = tid; i < m; i += NT) {
+            const int v = s.bvar[i];
+            if (v < n) s.key[v] = s.ba[i];
+        }
+        for (int j = n + tid; j < NP; j += NT) s.key[j] = 0.0;
+        __syncthreads();
+        if (g.x)
+            for (int j = tid; j < n; j += NT) g.x[(size_t)node * n + j] = s.key[j];
+        if (g.y) {
+            for (int i = tid; i < m; i += NT) g.y[(size_t)node * m + i] = 0.0;
+            __syncthreads();
+            for (int j = tid; j < n; j += NT)
+                if (s.nvar[j] >= n) g.y[(size_t)node * m + (s.nvar[j] - n)] = s.d[j];
+        }
+        if (g.vstat_out) {
+            int8_t *vo = g.vstat_out + (size_t)node * nv;
+            for (int i = tid; i < m; i += NT) vo[s.bvar[i]] = 1;
+            for (int j = tid; j < n; j += NT) vo[s.nvar[j]] = s.side[j] ? 2 : 3;
+        }
+        if (tid < 64) {
+            // obj = fold-in-half sum of c_j x_j over the padded power-of-two length
+            constexpr int PER = NP / 64;
+            double p[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int j = lane + 64 * k;
+                p[k] = j < n ? g.c[j] * s.key[j] : 0.0;
+            }
+#pragma unroll
+            for (int h = PER / 2; h >= 1; h >>= 1) {
+#pragma unroll
+                for (int k = 0; k < h; k++) p[k] = p[k] + p[k + h];
+            }
+            double sum = p[0];
+#pragma unroll
+            for (int h = 32; h >= 1; h >>= 1) sum = sum + __shfl_down(sum, h, 64);
+            if (tid == 0) {
+                if (g.obj) g.obj[node] = status == 1 ? INF : status == 2 ? -INF : sum;
+                if (g.status) g.status[node] = status;
+                if (g.iters) g.iters[node] = iters;
+                if (g.npivots) g.npivots[node] = npiv;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace mipx

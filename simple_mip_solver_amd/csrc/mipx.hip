@@ -1,0 +1,287 @@
+// mipx.hip -- host side of the C ABI declared in include/mipx.h (HIP runtime only: no torch,
+// no BLAS).  One context = one GPU + one stream.  No CPU fallback exists: every entry point
+// that computes requires a live HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mipx.h"
+#include "lp_kernel.hip.h"
+
+struct mipx_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+};
+
+struct mipx_problem {
+    mipx_ctx *ctx = nullptr;
+    int m = 0, n = 0;
+    double *dA = nullptr, *db = nullptr, *dc = nullptr;
+    // staging for the host-pointer entry point (grown on demand)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+namespace {
+
+int fail(mipx_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        ctx->err = what;
+        if (e != hipSuccess) {
+            ctx->err += ": ";
+            ctx->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                        \
+    do {                                                          \
+        hipError_t e_ = (call);                                   \
+        if (e_ != hipSuccess) return fail((ctx), MIPX_EHIP, #call, e_); \
+    } while (0)
+
+struct KernelCfg {
+    int mp, np, threads;
+    const char *name;
+    void (*launch)(const mipx::LpArgs &, int grid, hipStream_t);
+};
+
+template <int TBI, int TBJ, int R, int C>
+void launch_cfg(const mipx::LpArgs &a, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((mipx::lp_dual_simplex<TBI, TBJ, R, C>), dim3(grid), dim3(TBI * TBJ), 0, st, a);
+}
+
+// ordered by on-chip footprint; the first that fits (m <= mp, n <= np) is used
+const KernelCfg kCfgs[] = {
+    {32, 64, 64, "lp_dual_simplex<4,16,8,4>", launch_cfg<4, 16, 8, 4>},
+    {64, 128, 256, "lp_dual_simplex<8,32,8,4>", launch_cfg<8, 32, 8, 4>},
+    {128, 256, 512, "lp_dual_simplex<16,32,8,8>", launch_cfg<16, 32, 8, 8>},
+    {192, 256, 512, "lp_dual_simplex<16,32,12,8>", launch_cfg<16, 32, 12, 8>},
+};
+
+const KernelCfg *pick_cfg(int m, int n) {
+    for (const KernelCfg &c : kCfgs)
+        if (m <= c.mp && n <= c.np) return &c;
+    return nullptr;
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+int mipx_abi_version(void) { return 1; }
+
+int mipx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mipx_ctx_create(int device, mipx_ctx **out) {
+    if (!out) return MIPX_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MIPX_ENODEV;
+    if (device < 0 || device >= ndev) return MIPX_ENODEV;
+    mipx_ctx *ctx = new (std::nothrow) mipx_ctx();
+    if (!ctx) return MIPX_ENOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return MIPX_EHIP;
+    }
+    *out = ctx;
+    return MIPX_OK;
+}
+
+void mipx_ctx_destroy(mipx_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *mipx_last_error(const mipx_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int mipx_ctx_sync(mipx_ctx *ctx) {
+    if (!ctx) return MIPX_EINVAL;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MIPX_OK;
+}
+
+int mipx_problem_create(mipx_ctx *ctx, int m, int n, const double *A, const double *b,
+                        const double *c, mipx_problem **out) {
+    if (!ctx || !out || m < 0 || n <= 0 || !c || (m > 0 && (!A || !b)))
+        return fail(ctx, MIPX_EINVAL, "mipx_problem_create: bad argument");
+    *out = nullptr;
+    if (!pick_cfg(m, n)) return fail(ctx, MIPX_ETOOBIG, "mipx_problem_create: (m,n) exceeds on-chip tableau kernels");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mipx_problem *p = new (std::nothrow) mipx_problem();
+    if (!p) return fail(ctx, MIPX_ENOMEM, "mipx_problem_create: host alloc");
+    p->ctx = ctx;
+    p->m = m;
+    p->n = n;
+    const size_t am = (size_t)(m > 0 ? m : 1);
+    hipError_t e;
+    if ((e = hipMalloc(&p->dA, am * n * sizeof(double))) != hipSuccess ||
+        (e = hipMalloc(&p->db, am * sizeof(double))) != hipSuccess ||
+        (e = hipMalloc(&p->dc, (size_t)n * sizeof(double))) != hipSuccess) {
+        mipx_problem_destroy(p);
+        return fail(ctx, MIPX_EHIP, "mipx_problem_create: hipMalloc", e);
+    }
+    if (m > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(p->dA, A, (size_t)m * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(p->db, b, (size_t)m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(p->dc, c, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out = p;
+    return MIPX_OK;
+}
+
+void mipx_problem_destroy(mipx_problem *p) {
+    if (!p) return;
+    if (p->ctx) (void)hipSetDevice(p->ctx->device);
+    if (p->dA) (void)hipFree(p->dA);
+    if (p->db) (void)hipFree(p->db);
+    if (p->dc) (void)hipFree(p->dc);
+    if (p->scratch) (void)hipFree(p->scratch);
+    delete p;
+}
+
+int mipx_lp_solve_batch_dev(mipx_problem *p, int batch, const double *l, const double *u,
+                            const int8_t *vstat_in, int max_iter, int32_t *status, double *obj,
+                            double *x, double *y, int8_t *vstat_out, int32_t *iters,
+                            int32_t *npivots) {
+    if (!p) return MIPX_EINVAL;
+    mipx_ctx *ctx = p->ctx;
+    if (batch < 0 || (batch > 0 && (!l || !u))) return fail(ctx, MIPX_EINVAL, "mipx_lp_solve_batch_dev: bad argument");
+    if (batch == 0) return MIPX_OK;
+    const KernelCfg *cfg = pick_cfg(p->m, p->n);
+    if (!cfg) return fail(ctx, MIPX_ETOOBIG, "mipx_lp_solve_batch_dev: (m,n) too big");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mipx::LpArgs a;
+    a.m = p->m; a.n = p->n;
+    a.A = p->dA; a.b = p->db; a.c = p->dc;
+    a.l = l; a.u = u; a.vstat_in = vstat_in; a.max_iter = max_iter;
+    a.status = status; a.obj = obj; a.x = x; a.y = y; a.vstat_out = vstat_out;
+    a.iters = iters; a.npivots = npivots; a.batch = batch;
+    cfg->launch(a, batch, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return MIPX_OK;
+}
+
+int mipx_lp_solve_batch(mipx_problem *p, int batch, const double *l, const double *u,
+                        const int8_t *vstat_in, int max_iter, int32_t *status, double *obj,
+                        double *x, double *y, int8_t *vstat_out, int32_t *iters,
+                        int32_t *npivots) {
+    if (!p) return MIPX_EINVAL;
+    mipx_ctx *ctx = p->ctx;
+    if (batch < 0 || (batch > 0 && (!l || !u))) return fail(ctx, MIPX_EINVAL, "mipx_lp_solve_batch: bad argument");
+    if (batch == 0) return MIPX_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t B = (size_t)batch, n = (size_t)p->n, m = (size_t)p->m, nv = n + m;
+    // carve one staging allocation
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_l = carve(B * n * 8), o_u = carve(B * n * 8), o_vin = carve(B * nv),
+                 o_st = carve(B * 4), o_obj = carve(B * 8), o_x = carve(B * n * 8),
+                 o_y = carve(B * (m ? m : 1) * 8), o_vout = carve(B * nv), o_it = carve(B * 4),
+                 o_np = carve(B * 4);
+    if (off > p->scratch_bytes) {
+        if (p->scratch) (void)hipFree(p->scratch);
+        p->scratch = nullptr;
+        p->scratch_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&p->scratch, off));
+        p->scratch_bytes = off;
+    }
+    char *base = (char *)p->scratch;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_l, l, B * n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_u, u, B * n * 8, hipMemcpyHostToDevice, st));
+    if (vstat_in) HIP_TRY(ctx, hipMemcpyAsync(base + o_vin, vstat_in, B * nv, hipMemcpyHostToDevice, st));
+    int rc = mipx_lp_solve_batch_dev(
+        p, batch, (const double *)(base + o_l), (const double *)(base + o_u),
+        vstat_in ? (const int8_t *)(base + o_vin) : nullptr, max_iter, (int32_t *)(base + o_st),
+        (double *)(base + o_obj), (double *)(base + o_x), (double *)(base + o_y),
+        (int8_t *)(base + o_vout), (int32_t *)(base + o_it), (int32_t *)(base + o_np));
+    if (rc) return rc;
+    if (status) HIP_TRY(ctx, hipMemcpyAsync(status, base + o_st, B * 4, hipMemcpyDeviceToHost, st));
+    if (obj) HIP_TRY(ctx, hipMemcpyAsync(obj, base + o_obj, B * 8, hipMemcpyDeviceToHost, st));
+    if (x) HIP_TRY(ctx, hipMemcpyAsync(x, base + o_x, B * n * 8, hipMemcpyDeviceToHost, st));
+    if (y && m) HIP_TRY(ctx, hipMemcpyAsync(y, base + o_y, B * m * 8, hipMemcpyDeviceToHost, st));
+    if (vstat_out) HIP_TRY(ctx, hipMemcpyAsync(vstat_out, base + o_vout, B * nv, hipMemcpyDeviceToHost, st));
+    if (iters) HIP_TRY(ctx, hipMemcpyAsync(iters, base + o_it, B * 4, hipMemcpyDeviceToHost, st));
+    if (npivots) HIP_TRY(ctx, hipMemcpyAsync(npivots, base + o_np, B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return MIPX_OK;
+}
+
+int mipx_dev_alloc(mipx_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return MIPX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : 1));
+    return MIPX_OK;
+}
+
+int mipx_dev_free(mipx_ctx *ctx, void *dptr) {
+    if (!ctx) return MIPX_EINVAL;
+    if (!dptr) return MIPX_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipFree(dptr));
+    return MIPX_OK;
+}
+
+int mipx_memcpy_h2d(mipx_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return MIPX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MIPX_OK;
+}
+
+int mipx_memcpy_d2h(mipx_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return MIPX_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MIPX_OK;
+}
+
+int mipx_timer_start(mipx_ctx *ctx) {
+    if (!ctx) return MIPX_EINVAL;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return MIPX_OK;
+}
+
+int mipx_timer_stop(mipx_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return MIPX_EINVAL;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return MIPX_OK;
+}
+
+int mipx_kernel_name(int m, int n, char *buf, size_t buflen) {
+    const KernelCfg *cfg = pick_cfg(m, n);
+    if (!cfg) return MIPX_ETOOBIG;
+    if (!buf || buflen == 0) return MIPX_EINVAL;
+    std::snprintf(buf, buflen, "%s", cfg->name);
+    return MIPX_OK;
+}
+
+}  // extern "C"

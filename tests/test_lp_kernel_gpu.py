@@ -1,0 +1,129 @@
+"""GPU parity of K1 (batched dual simplex) against the CPU oracle, through the C ABI.
+
+Bar: bit-exact status / basis / iteration counts / x / objective (integer and f64 alike: the
+kernel follows the oracle's canonical operation order).  Comparisons use == so that -0.0 == 0.0.
+"""
+import numpy as np
+import pytest
+
+from simple_mip_solver_amd import _ffi
+from simple_mip_solver_amd.generators import random_dense_milp_arrays
+
+pytestmark = pytest.mark.gpu
+INF = np.inf
+
+
+def assert_same(g, o, what=''):
+    assert np.array_equal(g['status'], o['status']), f'{what} status'
+    assert np.array_equal(g['iters'], o['iters']), f'{what} iters'
+    assert np.array_equal(g['npivots'], o['npivots']), f'{what} npivots'
+    assert np.array_equal(g['vstat'], o['vstat']), f'{what} basis'
+    ok = (g['status'] != 1)
+    fin = (g['status'] == 0) | (g['status'] == 3)
+    assert np.array_equal(g['x'][fin], o['x'][fin]), f'{what} x'
+    assert np.array_equal(g['obj'][ok], o['obj'][ok]), f'{what} obj'
+    assert np.all(np.isposinf(g['obj'][~ok]))
+    assert np.array_equal(g['y'][fin], o['y'][fin]), f'{what} duals'
+
+
+SMALL = {
+    'no_branch': (-np.eye(3), [-1, -1, -1], [-1, -1, 0], [0, 0, 0], [INF] * 3),
+    'small_branch': ([[-1, 0, -1], [0, -1, 0]], [-1.5, -1.25], [-1, -1, -1], [0, 0, 0], [10] * 3),
+    'infeasible': ([[-1, -1, 0]], [1], [-1, -1, 0], [0, 0, 0], [INF] * 3),
+    'unbounded': ([[-1, 1], [1, -1]], [-.5, -.5], [-1, -1], [0, 0], [INF] * 2),
+    'cut2': ([[-4, -1], [-1, -4], [-1, 1]], [-28, -27, -1], [-2, -5], [0, 0], [INF] * 2),
+    'cut3': ([[-3, -4], [-5, -10], [-1, -2]], [-10, -8, -1.2], [-8, -12], [0, 0], [INF] * 2),
+}
+
+
+@pytest.mark.parametrize('name', sorted(SMALL))
+def test_small_models_match_oracle(name, gpu_ctx, oracle):
+    A, b, c, l, u = [np.asarray(a, float) for a in SMALL[name]]
+    p = _ffi.Problem(gpu_ctx, A, b, c)
+    g = p.solve_batch(l[None], u[None])
+    o = oracle.lp_solve_batch(A, b, c, l[None], u[None])
+    assert_same(g, o, name)
+
+
+def test_small_branch_pinned_root(gpu_ctx):
+    # test_base_node.py:406-416 (reference): objective -2.75 at x = [0, 1.25, 1.5]
+    A, b, c, l, u = [np.asarray(a, float) for a in SMALL['small_branch']]
+    g = _ffi.Problem(gpu_ctx, A, b, c).solve_batch(l[None], u[None])
+    assert g['status'][0] == 0 and g['obj'][0] == -2.75
+    assert np.array_equal(g['x'][0], [0, 1.25, 1.5])
+
+
+def _children(A, b, c, l, u, root, k):
+    """2k child nodes of a solved root: branch on the k most fractional variables."""
+    x = root['x'][0]
+    frac = np.minimum(x - np.floor(x), np.ceil(x) - x)
+    idx = np.argsort(-frac, kind='stable')[:k]
+    ls, us = [], []
+    for j in idx:
+        if frac[j] <= 1e-4:
+            continue
+        l2, u2 = l.copy(), u.copy()
+        u2[j] = np.floor(x[j])
+        ls.append(l2); us.append(u2)
+        l2, u2 = l.copy(), u.copy()
+        l2[j] = np.ceil(x[j])
+        ls.append(l2); us.append(u2)
+    L, U = np.array(ls), np.array(us)
+    V = np.repeat(root['vstat'], len(L), axis=0)
+    return L, U, V
+
+
+@pytest.mark.parametrize('n,m,seeds', [(64, 32, range(16)), (20, 10, range(8)), (100, 40, range(4))])
+def test_cold_roots_batch(n, m, seeds, gpu_ctx, oracle):
+    # config C2 shape: independent instances, cold start (each instance is its own problem)
+    for seed in seeds:
+        A, b, c, l, u, _ = random_dense_milp_arrays(n, m, seed=seed)
+        p = _ffi.Problem(gpu_ctx, A, b, c)
+        g = p.solve_batch(l[None], u[None])
+        o = oracle.lp_solve_batch(A, b, c, l[None], u[None])
+        assert_same(g, o, f'{n}x{m} seed {seed}')
+        assert g['status'][0] == 0
+
+
+def test_s3_root_children_and_probes(gpu_ctx, oracle):
+    # config C3 shape: 256 x 128, cold root, warm-started children, 5-iteration probes
+    A, b, c, l, u, _ = random_dense_milp_arrays(256, 128, seed=0)
+    p = _ffi.Problem(gpu_ctx, A, b, c)
+    root = p.solve_batch(l[None], u[None])
+    oroot = oracle.lp_solve_batch(A, b, c, l[None], u[None])
+    assert_same(root, oroot, 'root')
+    L, U, V = _children(A, b, c, l, u, root, 24)
+    g = p.solve_batch(L, U, V)
+    o = oracle.lp_solve_batch(A, b, c, L, U, V)
+    assert_same(g, o, 'children')
+    assert np.all(g['obj'][g['status'] == 0] >= root['obj'][0] - 1e-9)
+    g5 = p.solve_batch(L, U, V, max_iter=5)
+    o5 = oracle.lp_solve_batch(A, b, c, L, U, V, max_iter=5)
+    assert_same(g5, o5, 'probes')
+    assert set(np.unique(g5['status'])) <= {0, 1, 3}
+    # grandchildren from each child's own basis (deeper refactorisations)
+    ok = np.where(g['status'] == 0)[0][:8]
+    for k in ok:
+        one = {key: val[k:k + 1] for key, val in g.items()}
+        L2, U2, V2 = _children(A, b, c, L[k], U[k], one, 4)
+        if len(L2) == 0:
+            continue
+        g2 = p.solve_batch(L2, U2, V2)
+        o2 = oracle.lp_solve_batch(A, b, c, L2, U2, V2)
+        assert_same(g2, o2, f'grandchildren of {k}')
+
+
+def test_with_extra_rows_uses_tall_kernel(gpu_ctx, oracle):
+    # m > 128 (cut rows appended) dispatches to the R=12 instantiation
+    A, b, c, l, u, _ = random_dense_milp_arrays(200, 150, seed=3)
+    assert '12' in _ffi.kernel_name(150, 200)
+    p = _ffi.Problem(gpu_ctx, A, b, c)
+    g = p.solve_batch(l[None], u[None])
+    o = oracle.lp_solve_batch(A, b, c, l[None], u[None])
+    assert_same(g, o, 'tall')
+
+
+def test_too_big_fails_loudly(gpu_ctx):
+    A, b, c, l, u, _ = random_dense_milp_arrays(1024, 512, seed=0)
+    with pytest.raises(_ffi.MipxError, match='MIPX_ETOOBIG'):
+        _ffi.Problem(gpu_ctx, A, b, c)
