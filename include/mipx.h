@@ -108,6 +108,14 @@ int mipx_memcpy_d2h(mipx_ctx *ctx, void *dst_host, const void *src_dev, size_t b
 int mipx_timer_start(mipx_ctx *ctx);
 int mipx_timer_stop(mipx_ctx *ctx, float *ms);
 
+/*
+ * Test hook: after mipx_debug_enable(p) every solve also dumps the final simplex state of node 0
+ * of the batch: T (m x n row-major), vec = [d (n) | beta0 (m) | ba (m) | bb (m)],
+ * idx = [nvar (n) | bvar (m) | side (n)].  Used by the tableau-parity tests only.
+ */
+int mipx_debug_enable(mipx_problem *p);
+int mipx_debug_read(mipx_problem *p, double *T, double *vec, int32_t *idx);
+
 /* Name of the kernel instantiation that (m, n) dispatches to, e.g. "lp_dual_simplex<16,32,8,8>". */
 int mipx_kernel_name(int m, int n, char *buf, size_t buflen);
 

@@ -55,6 +55,13 @@
 #define ST_UPPER 2
 #define ST_LOWER 3
 
+/* optional dump of the final simplex state (set by tests through mipx_oracle_set_dump) */
+static double *g_dump_T = 0, *g_dump_vec = 0;
+static int32_t *g_dump_idx = 0;
+void mipx_oracle_set_dump(double *T, double *vec, int32_t *idx) {
+    g_dump_T = T; g_dump_vec = vec; g_dump_idx = idx;
+}
+
 static int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 /* fold-in-half summation tree over a power-of-two length buffer (destroys p) */
@@ -292,6 +299,16 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
         }
     }
 
+    if (g_dump_T) {
+        memcpy(g_dump_T, t.T, sizeof(double) * (size_t)m * n);
+        for (int j = 0; j < n; j++) {
+            g_dump_vec[j] = t.d[j]; g_dump_idx[j] = t.nvar[j]; g_dump_idx[n + m + j] = nb_up[j];
+        }
+        for (int i = 0; i < m; i++) {
+            g_dump_vec[n + i] = t.beta0[i]; g_dump_vec[n + m + i] = ba[i];
+            g_dump_vec[n + 2 * m + i] = bb[i]; g_dump_idx[n + i] = t.bvar[i];
+        }
+    }
     /* 4. outputs */
     if (x_out || obj_out) {
         double *x = (double *)malloc(sizeof(double) * (size_t)n);

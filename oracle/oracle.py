@@ -106,3 +106,18 @@ def pseudo_cost_update(cost, times, status, objective, dual_bound, variable_chan
                                          C.c_double(objective), C.c_double(dual_bound),
                                          C.c_double(variable_change))
     return cc.value, tt.value
+
+
+def debug_dump(A, b, c, l, u, vstat=None, max_iter=0):
+    """Solve one LP and return the final tableau state (mirror of _ffi.debug_dump)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    m, n = A.shape
+    T = np.zeros((m, n)); vec = np.zeros(n + 3 * m); idx = np.zeros(2 * n + m, np.int32)
+    lib().mipx_oracle_set_dump(_p(T, _dp), _p(vec, _dp), _p(idx, _i32p))
+    try:
+        res = lp_solve_batch(A, b, c, np.asarray(l, float)[None], np.asarray(u, float)[None],
+                             None if vstat is None else np.asarray(vstat, np.int8)[None], max_iter)
+    finally:
+        lib().mipx_oracle_set_dump(None, None, None)
+    return res, dict(T=T, d=vec[:n], beta0=vec[n:n + m], ba=vec[n + m:n + 2 * m],
+                     bb=vec[n + 2 * m:], nvar=idx[:n], bvar=idx[n:n + m], side=idx[n + m:])

@@ -20,7 +20,7 @@ SYMBOLS = [
     'mipx_last_error', 'mipx_ctx_sync', 'mipx_problem_create', 'mipx_problem_destroy',
     'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_dev_alloc', 'mipx_dev_free',
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
-    'mipx_kernel_name',
+    'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -215,3 +215,18 @@ def default_context():
     if _default_ctx is None:
         _default_ctx = Context(int(os.environ.get('LOCAL_RANK', '0')))
     return _default_ctx
+
+
+def debug_dump(problem, l, u, vstat=None, max_iter=0):
+    """Test hook: solve one LP and return the kernel's final tableau state (see mipx.h)."""
+    L = lib()
+    L.mipx_debug_enable.argtypes = [_vp]
+    L.mipx_debug_read.argtypes = [_vp, _vp, _vp, _vp]
+    problem.ctx.check(L.mipx_debug_enable(problem._h), 'mipx_debug_enable')
+    res = problem.solve_batch(np.asarray(l, float)[None], np.asarray(u, float)[None],
+                              None if vstat is None else np.asarray(vstat, np.int8)[None], max_iter)
+    m, n = problem.m, problem.n
+    T = np.zeros((m, n)); vec = np.zeros(n + 3 * m); idx = np.zeros(2 * n + m, np.int32)
+    problem.ctx.check(L.mipx_debug_read(problem._h, _ptr(T), _ptr(vec), _ptr(idx)), 'mipx_debug_read')
+    return res, dict(T=T, d=vec[:n], beta0=vec[n:n + m], ba=vec[n + m:n + 2 * m],
+                     bb=vec[n + 2 * m:], nvar=idx[:n], bvar=idx[n:n + m], side=idx[n + m:])

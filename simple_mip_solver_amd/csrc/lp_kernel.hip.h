@@ -44,6 +44,10 @@ struct LpArgs {
     int32_t *iters;
     int32_t *npivots;
     int batch;
+    // optional debug dump of the final tableau state of node 0 (nullptr in production)
+    double *dbg_T;      // m x n row-major
+    double *dbg_vec;    // [d (n) | beta0 (m) | ba (m) | bb (m)]
+    int32_t *dbg_idx;   // [nvar (n) | bvar (m) | side (n)]
 };
 
 struct Best {
@@ -59,6 +63,15 @@ __device__ __forceinline__ bool better(const Best &a, const Best &b) {
     return a.lo < b.lo;
 }
 
+// branch-free "cur = valid && better(cand, cur) ? cand : cur"
+__device__ __forceinline__ void take(Best &cur, const Best &cand, bool valid) {
+    const bool b = valid && better(cand, cur);
+    cur.hi = b ? cand.hi : cur.hi;
+    cur.key = b ? cand.key : cur.key;
+    cur.lo = b ? cand.lo : cur.lo;
+    cur.idx = b ? cand.idx : cur.idx;
+}
+
 __device__ __forceinline__ Best wave_best(Best v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -67,7 +80,7 @@ __device__ __forceinline__ Best wave_best(Best v) {
         o.key = __shfl_xor(v.key, off);
         o.lo = __shfl_xor(v.lo, off);
         o.idx = __shfl_xor(v.idx, off);
-        if (better(o, v)) v = o;
+        take(v, o, true);
     }
     return v;
 }
@@ -292,12 +305,11 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                 Best best{-1, 0.0, 0, -1}, fb{-1, 0.0, 0, -1};
                 for (int i = lane; i < m; i += 64) {
                     const int bv = s.bvar[i];
-                    if (bv < n) continue;
                     const double a = fabs(s.alpha[i]);
-                    if (!(a > kPivTol)) continue;
-                    Best cand{0, a, i, i};
-                    if (better(cand, fb)) fb = cand;
-                    if (!s.wantb[bv] && better(cand, best)) best = cand;
+                    const bool ok = bv >= n && a > kPivTol;
+                    const Best cand{0, a, i, i};
+                    take(fb, cand, ok);
+                    take(best, cand, ok && !s.wantb[bv >= n ? bv : n]);
                 }
                 best = wave_best(best);
                 if (__builtin_amdgcn_readfirstlane(best.hi) < 0) best = wave_best(fb);
@@ -362,6 +374,8 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                     s.ba[i] = s.beta0[i] - sa;
                     s.bb[i] = 0.0 - sb;
                 }
+                // keep the rows' temporaries from being interleaved (register pressure)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
@@ -387,9 +401,8 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                     if (a < lo - kPTol) { level = 1; viol = lo - a; sg = 1; }
                     else if (!isinf(up) && a > up + kPTol) { level = 1; viol = a - up; sg = -1; }
                 }
-                if (level == 0) continue;
-                Best cand{level, viol, v, sg > 0 ? i : (i | (1 << 30))};
-                if (better(cand, best)) best = cand;
+                const Best cand{level, viol, v, sg > 0 ? i : (i | (1 << 30))};
+                take(best, cand, level > 0);
             }
             best = wave_best(best);
             if (__builtin_amdgcn_readfirstlane(best.hi) < 0) {
@@ -423,9 +436,8 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
             __syncthreads();
             Best mn{-1, 0.0, 0, -1};
             for (int j = lane; j < n; j += 64) {
-                if (s.aabs[j] < 0.0) continue;
-                Best cand{0, -s.key[j], s.nvar[j], j};
-                if (better(cand, mn)) mn = cand;
+                const Best cand{0, -s.key[j], s.nvar[j], j};
+                take(mn, cand, s.aabs[j] >= 0.0);
             }
             mn = wave_best(mn);
             if (__builtin_amdgcn_readfirstlane(mn.hi) < 0) { status = 1; break; }
@@ -434,10 +446,9 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
             Best bq{-1, 0.0, 0, -1};
             for (int j = lane; j < n; j += 64) {
                 const double aa = s.aabs[j];
-                if (aa < 0.0) continue;
-                if (j != jmin && s.dje[j] > thmax * aa) continue;
-                Best cand{0, aa, s.nvar[j], j};
-                if (better(cand, bq)) bq = cand;
+                const bool ok = aa >= 0.0 && (j == jmin || !(s.dje[j] > thmax * aa));
+                const Best cand{0, aa, s.nvar[j], j};
+                take(bq, cand, ok);
             }
             bq = wave_best(bq);
             const int q = __builtin_amdgcn_readfirstlane(bq.idx);
@@ -488,6 +499,27 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
             int8_t *vo = g.vstat_out + (size_t)node * nv;
             for (int i = tid; i < m; i += NT) vo[s.bvar[i]] = 1;
             for (int j = tid; j < n; j += NT) vo[s.nvar[j]] = s.side[j] ? 2 : 3;
+        }
+        if (g.dbg_T && node == 0) {
+#pragma unroll
+            for (int ii = 0; ii < R; ii++) {
+#pragma unroll
+                for (int jj = 0; jj < C; jj++) {
+                    const int i = bi + TBI * ii, j = bj + TBJ * jj;
+                    if (i < m && j < n) g.dbg_T[(size_t)i * n + j] = T[ii][jj];
+                }
+            }
+            for (int j = tid; j < n; j += NT) {
+                g.dbg_vec[j] = s.d[j];
+                g.dbg_idx[j] = s.nvar[j];
+                g.dbg_idx[n + m + j] = s.side[j];
+            }
+            for (int i = tid; i < m; i += NT) {
+                g.dbg_vec[n + i] = s.beta0[i];
+                g.dbg_vec[n + m + i] = s.ba[i];
+                g.dbg_vec[n + 2 * m + i] = s.bb[i];
+                g.dbg_idx[n + i] = s.bvar[i];
+            }
         }
         if (tid < 64) {
             // obj = fold-in-half sum of c_j x_j over the padded power-of-two length

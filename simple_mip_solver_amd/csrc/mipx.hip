@@ -26,6 +26,9 @@ struct mipx_problem {
     // staging for the host-pointer entry point (grown on demand)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    // debug dump buffers (device), enabled by mipx_debug_enable
+    double *dbg_T = nullptr, *dbg_vec = nullptr;
+    int32_t *dbg_idx = nullptr;
 };
 
 namespace {
@@ -160,6 +163,9 @@ void mipx_problem_destroy(mipx_problem *p) {
     if (p->db) (void)hipFree(p->db);
     if (p->dc) (void)hipFree(p->dc);
     if (p->scratch) (void)hipFree(p->scratch);
+    if (p->dbg_T) (void)hipFree(p->dbg_T);
+    if (p->dbg_vec) (void)hipFree(p->dbg_vec);
+    if (p->dbg_idx) (void)hipFree(p->dbg_idx);
     delete p;
 }
 
@@ -180,6 +186,7 @@ int mipx_lp_solve_batch_dev(mipx_problem *p, int batch, const double *l, const d
     a.l = l; a.u = u; a.vstat_in = vstat_in; a.max_iter = max_iter;
     a.status = status; a.obj = obj; a.x = x; a.y = y; a.vstat_out = vstat_out;
     a.iters = iters; a.npivots = npivots; a.batch = batch;
+    a.dbg_T = p->dbg_T; a.dbg_vec = p->dbg_vec; a.dbg_idx = p->dbg_idx;
     cfg->launch(a, batch, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return MIPX_OK;
@@ -228,6 +235,29 @@ int mipx_lp_solve_batch(mipx_problem *p, int batch, const double *l, const doubl
     if (iters) HIP_TRY(ctx, hipMemcpyAsync(iters, base + o_it, B * 4, hipMemcpyDeviceToHost, st));
     if (npivots) HIP_TRY(ctx, hipMemcpyAsync(npivots, base + o_np, B * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    return MIPX_OK;
+}
+
+int mipx_debug_enable(mipx_problem *p) {
+    if (!p) return MIPX_EINVAL;
+    mipx_ctx *ctx = p->ctx;
+    if (p->dbg_T) return MIPX_OK;
+    const size_t m = p->m ? p->m : 1, n = p->n;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(&p->dbg_T, m * n * 8));
+    HIP_TRY(ctx, hipMalloc(&p->dbg_vec, (n + 3 * m) * 8));
+    HIP_TRY(ctx, hipMalloc(&p->dbg_idx, (2 * n + m) * 4));
+    return MIPX_OK;
+}
+
+int mipx_debug_read(mipx_problem *p, double *T, double *vec, int32_t *idx) {
+    if (!p || !p->dbg_T) return MIPX_EINVAL;
+    mipx_ctx *ctx = p->ctx;
+    const size_t m = p->m, n = p->n;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (T) HIP_TRY(ctx, hipMemcpy(T, p->dbg_T, m * n * 8, hipMemcpyDeviceToHost));
+    if (vec) HIP_TRY(ctx, hipMemcpy(vec, p->dbg_vec, (n + 3 * m) * 8, hipMemcpyDeviceToHost));
+    if (idx) HIP_TRY(ctx, hipMemcpy(idx, p->dbg_idx, (2 * n + m) * 4, hipMemcpyDeviceToHost));
     return MIPX_OK;
 }
 
