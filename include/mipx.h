@@ -72,7 +72,7 @@ void mipx_problem_destroy(mipx_problem *p);
  *   vstat_in    batch x (n+m) warm-start basis (base_node.py:608 setBasisStatus) or NULL = cold
  *   max_iter    <= 0: run to termination; > 0: lp.maxNumIteration (base_node.py:645)
  *   status      batch       Clp status code
- *   obj         batch       c'x (+inf if status 1, -inf if status 2)
+ *   obj         batch       c'x (+inf if status 1; for status 2 the symbolic bound M is reported as 1e10)
  *   x           batch x n   primalVariableSolution
  *   y           batch x m   dualConstraintSolution (row duals; 0 where the row's slack is basic)
  *   vstat_out   batch x (n+m) getBasisStatus

@@ -50,6 +50,8 @@
 #define MIPX_DTOL 1e-7   /* dual feasibility tolerance (Clp default dualTolerance)     */
 #define MIPX_PIVTOL 1e-9 /* smallest acceptable |pivot|                                 */
 #define MIPX_BTOL 1e-9   /* zero test on the M component                                */
+#define MIPX_MREPORT 1e10 /* value substituted for the symbolic bound M when reporting x of an
+                             unbounded LP (Clp reports its artificial dual bound likewise) */
 
 #define ST_BASIC 1
 #define ST_UPPER 2
@@ -117,7 +119,7 @@ static void tab_pivot(tab_t *t, int r, int q) {
  * vstat_in: n+m Clp status codes (1 basic, 2 at upper, 3 at lower, anything else = at lower)
  *           or NULL for a cold start from the slack basis.
  * max_iter <= 0: no limit other than the internal cap.
- * Outputs: status (0/1/2/3), obj (c'x; +inf if infeasible, -inf if unbounded), x[n],
+ * Outputs: status (0/1/2/3), obj (c.x; +inf if infeasible; M := 1e10 if unbounded), x[n],
  *          y[m] row duals, dj[n] reduced costs of structurals (0 for basic), vstat_out[n+m],
  *          iters (dual simplex iterations), npivots (refactor + simplex pivots).
  * Any output pointer may be NULL.
@@ -314,15 +316,14 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
         double *x = (double *)malloc(sizeof(double) * (size_t)n);
         for (int j = 0; j < n; j++) {
             int v = t.nvar[j];
-            if (v < n) x[v] = nb_up[j] == 2 ? INFINITY : va[j];
+            if (v < n) x[v] = nb_up[j] == 2 ? MIPX_MREPORT : va[j];
         }
         for (int i = 0; i < m; i++) {
             int v = t.bvar[i];
-            if (v < n) x[v] = ba[i];
+            if (v < n) x[v] = fma(bb[i], MIPX_MREPORT, ba[i]);
         }
         if (obj_out) {
             if (status == 1) *obj_out = INFINITY;
-            else if (status == 2) *obj_out = -INFINITY;
             else {
                 for (int j = 0; j < n; j++) buf[j] = c[j] * x[j];
                 for (int j = n; j < n2; j++) buf[j] = 0.0;

@@ -1,0 +1,251 @@
+"""BranchAndBound driver and its tree.
+
+Mirror of simple_mip_solver/algorithms/branch_and_bound.py:19-306: same constructor keywords,
+validation messages, `solve()` semantics (re-entrant: a second call continues from the live
+queue), status strings, `_kwargs` protocol and tree bookkeeping.  Nodes are duck-typed plugin
+objects exactly as in the reference; the stock node classes of this package do their bounding on
+the MI355X engine.
+
+Deviations: wall-clock instead of CPU-clock time limits (GPU work does not advance
+time.process_time); the root dual bound used by the gap test is tracked incrementally instead of
+re-scanning every tree vertex up to four times per iteration (reference :199-213, :226-229) --
+same value, O(log N) instead of O(N); find_parameterized_dual_bound (:314-417) is out of scope.
+"""
+import heapq
+from queue import PriorityQueue
+import time
+
+from simple_mip_solver_amd.algorithms.base_algorithm import BaseAlgorithm
+from simple_mip_solver_amd.nodes.base_node import BaseNode
+from simple_mip_solver_amd.utils.binary_tree import BinaryTree
+
+INF = float('inf')
+
+
+def _leaf_value(node):
+    return node.objective_value if node.objective_value is not None else node.dual_bound
+
+
+class BranchAndBoundTree(BinaryTree):
+    """Search tree; every vertex carries its Node under attr['node'] (reference :19-108)."""
+
+    def get_leaves(self, subtree_root_id, depth=None, keep='all'):
+        """Leaves of the subtree under subtree_root_id, optionally after cutting everything more
+        than `depth` edges below it.  keep: 'all' | 'feasible' | 'not infeasible'."""
+        assert subtree_root_id in self, 'subtree_root_id must belong to the tree'
+        assert keep in ['all', 'feasible', 'not infeasible'], \
+            "keep is one of 'all', 'feasible', or 'not infeasible'"
+        everyone = [v.attr['node'] for v in self.nodes.values()]
+        if depth is None:
+            found = [n for n in everyone if n.is_leaf and subtree_root_id in n.lineage]
+        else:
+            assert isinstance(depth, int) and depth >= 0, 'depth is a nonnegative integer'
+            if depth == 0:
+                found = self.get_node_instances([subtree_root_id])
+            elif depth == 1:
+                found = self.get_node_instances(self.get_children(subtree_root_id))
+            else:
+                shallow = [n for n in everyone
+                           if n.is_leaf and subtree_root_id in n.lineage[-depth:]]
+                at_depth = [n for n in everyone if len(n.lineage) >= depth + 1 and
+                            n.lineage[-(depth + 1)] == subtree_root_id]
+                found = shallow + at_depth
+        if keep == 'feasible':
+            return [n for n in found if n.lp_feasible]
+        if keep == 'not infeasible':
+            return [n for n in found if n.lp_feasible is not False]
+        return found
+
+    def get_disjunction(self, subtree_root_id):
+        """{leaf idx: (lower bounds, upper bounds)} over the not-infeasible leaves."""
+        return {n.idx: (n.lp.variablesLower.copy(), n.lp.variablesUpper.copy())
+                for n in self.get_leaves(subtree_root_id, keep='not infeasible')}
+
+    def get_node_instances(self, node_ids):
+        single = isinstance(node_ids, int)
+        if single:
+            node_ids = [node_ids]
+        else:
+            assert hasattr(node_ids, '__iter__') and not isinstance(node_ids, str), \
+                'node_ids must be an integer or iterable (that is not a string)'
+            node_ids = list(node_ids)
+        missing = set(node_ids) - set(self.nodes)
+        assert not missing, f'the following node_ids are not in the tree: {missing}'
+        found = [self.nodes[i].attr.get('node') for i in node_ids]
+        assert all(n is not None for n in found), \
+            'each vertex in the branch and bound tree must have an attribute for a node instance'
+        return found[0] if single else found
+
+    def subtree_dual_bound(self, subtree_root_id, depth=None):
+        """min over the subtree's leaves of their LP objective (or inherited bound if unsolved)."""
+        assert subtree_root_id in self, 'subtree_root_id must belong to the tree'
+        return min(_leaf_value(n) for n in self.get_leaves(subtree_root_id, depth=depth))
+
+
+class _LeafBounds:
+    """Lazy min-heap over leaf values: same answer as scanning all leaves of the root."""
+
+    def __init__(self):
+        self._heap = []
+        self._count = 0
+
+    def push(self, node):
+        self._count += 1
+        heapq.heappush(self._heap, (_leaf_value(node), self._count, node))
+
+    def minimum(self):
+        while self._heap:
+            value, _, node = self._heap[0]
+            if node.is_leaf and _leaf_value(node) == value:
+                return value
+            heapq.heappop(self._heap)  # stale: the node was branched on or re-valued
+        return INF
+
+
+class BranchAndBound(BaseAlgorithm):
+    """Solve a MILP by branch and bound with the bound / branch / search rules of a Node class."""
+
+    _node_attributes = ['dual_bound', 'objective_value', 'solution', 'lp_feasible',
+                        'mip_feasible', 'search_method', 'branch_method', 'idx', 'lp',
+                        'is_leaf', 'lineage']
+    _node_funcs = ['bound', 'branch', '__lt__', '__eq__']
+    _queue_funcs = ['put', 'get', 'empty']
+
+    def __init__(self, model, Node=BaseNode, node_queue=None, node_limit=INF, mip_gap=.0001,
+                 logging=False, max_run_time=INF, initial_primal_bound=INF, **kwargs):
+        """All problems are converted to minimisation with A x >= b on the way in.  **kwargs are
+        handed to every bound()/branch() call and refreshed from what those calls return
+        (e.g. pseudo_costs={}, strong_branch_iters=5, gomory_cuts=False)."""
+        node_queue = node_queue or PriorityQueue()
+        super().__init__(model=model, Node=Node, node_attributes=self._node_attributes,
+                         node_funcs=self._node_funcs, **kwargs)
+
+        for func in self._queue_funcs:
+            assert callable(getattr(node_queue, func, None)), f'node_queue needs a {func} function'
+        assert node_limit == INF or (isinstance(node_limit, int) and node_limit > 0), \
+            "node limit must be positive integer or infinity"
+        assert 0 <= mip_gap < 1, 'mip_gap is a ratio between 0 and 1'
+        assert isinstance(logging, bool), 'logging is boolean'
+        assert max_run_time > 0, 'max_run_time is positive value'
+        assert initial_primal_bound > -INF, 'initial_primal_bound is real or infinite'
+        special_keys = {'right', 'left', 'cuts'}
+        assert set(kwargs.keys()).isdisjoint(special_keys), \
+            f'keys {special_keys} are saved for later use'
+        assert all(isinstance(k, str) for k in kwargs), 'kwargs keys must be strings'
+
+        self._node_queue = node_queue
+        self._unbounded = None
+        self._best_solution = None
+        self.solution = None
+        self.status = 'unsolved'
+        self.objective_value = None
+        self.primal_bound = initial_primal_bound
+        self.node_limit = node_limit
+        self.tree = BranchAndBoundTree()
+        self.tree.add_root(self.root_node.idx, node=self.root_node)
+        self._leaf_bounds = _LeafBounds()
+        self._leaf_bounds.push(self.root_node)
+        self.solve_time = 0
+        self.mip_gap = mip_gap
+        self.logging = logging
+        self.max_run_time = max_run_time
+
+    @property
+    def dual_bound(self):
+        return self._leaf_bounds.minimum()
+
+    @property
+    def current_gap(self):
+        """|primal - dual| / |primal|; None until an incumbent exists (reference :203-213)."""
+        primal, dual = self.primal_bound, self.dual_bound
+        if primal == dual == 0:
+            return 0
+        if primal == 0:
+            return INF
+        if primal == INF:
+            return None
+        return abs(primal - dual) / abs(primal)
+
+    def _gap_closed(self):
+        gap = self.current_gap
+        return gap is not None and gap <= self.mip_gap
+
+    def solve(self):
+        """Run (or continue) the search until the queue empties, the problem proves unbounded, or
+        the node / gap / time limit is hit (reference :215-241)."""
+        start = time.perf_counter()
+        if self.status == 'unsolved':
+            self._node_queue.put(self.root_node)
+
+        while not (self._node_queue.empty() or self._unbounded or
+                   self.evaluated_nodes >= self.node_limit or self._gap_closed() or
+                   time.perf_counter() - start > self.max_run_time):
+            if self.logging and self.evaluated_nodes % 100 == 0:
+                print(f'{self.evaluated_nodes} nodes evaluated gap: {self.current_gap}')
+            self._evaluate_node(self._node_queue.get())
+
+        self.solve_time += time.perf_counter() - start
+        if self._unbounded:
+            self.status = 'unbounded'
+        elif self._node_queue.empty() and self.primal_bound == INF:
+            self.status = 'infeasible'
+        elif self.primal_bound < INF and self.current_gap <= self.mip_gap:
+            self.status = 'optimal'
+        else:
+            self.status = 'stopped on iterations or time'
+        self.solution = self._best_solution
+        self.objective_value = self.primal_bound
+
+    def _evaluate_node(self, node):
+        """Bound the node unless its inherited bound already prunes it; record an incumbent or
+        branch (reference :243-266)."""
+        if not node.dual_bound < self.primal_bound:
+            return
+        self.evaluated_nodes += 1
+        self._process_bound_rtn(node.bound(**self._kwargs))
+        self._leaf_bounds.push(node)  # the node now carries its own LP objective
+
+        # like the reference, an unbounded relaxation is taken to mean an unbounded MILP
+        if node.unbounded:
+            self._unbounded = True
+
+        if node.lp_feasible and node.objective_value < self.primal_bound:
+            if node.mip_feasible:
+                self._best_solution = node.solution
+                self.primal_bound = node.objective_value
+            else:
+                self._process_branch_rtn(node.idx, node.branch(**self._kwargs))
+
+    def _process_branch_rtn(self, parent_id, rtn):
+        """Queue the two children ('left' = down, 'right' = up), hang them in the tree, merge the
+        remaining keys into the kwargs (reference :268-289)."""
+        assert isinstance(rtn, dict), 'rtn must be a dictionary'
+        assert isinstance(parent_id, int), 'parent_id must be integer'
+        assert parent_id in self.tree, 'parent must already exist in tree'
+        for direction in ['left', 'right']:
+            assert direction in rtn, f'{direction} must be in the returned dict'
+            child = rtn.pop(direction)
+            assert isinstance(child, self._Node), \
+                f'{direction} value must be type {type(self._Node)}'
+            assert child.idx not in self.tree, 'please give unique node ID'
+            self._node_queue.put(child)
+            getattr(self.tree, f'add_{direction}_child')(child.idx, parent_id, node=child)
+            self._leaf_bounds.push(child)
+        self._process_rtn(rtn)
+
+    def _process_bound_rtn(self, rtn):
+        """Share returned 'cuts' with every queued node's cut pool, merge the rest into the
+        kwargs (reference :291-306)."""
+        assert isinstance(rtn, dict), 'rtn must be a dictionary'
+        cuts = rtn.get('cuts')
+        if cuts:
+            for name, (pi, pi0) in cuts.items():
+                for queued in self._node_queue.queue:
+                    queued.cut_pool[name] = (pi, pi0)
+            del rtn['cuts']
+        self._process_rtn(rtn)
+
+    def find_parameterized_dual_bound(self, b):
+        raise NotImplementedError(
+            'find_parameterized_dual_bound (reference branch_and_bound.py:314-417) is outside '
+            'the node hot path this package accelerates; see DESIGN.md "out of scope"')

@@ -29,6 +29,7 @@ constexpr double kPTol = 1e-7;
 constexpr double kDTol = 1e-7;
 constexpr double kPivTol = 1e-9;
 constexpr double kBTol = 1e-9;
+constexpr double kMReport = 1e10;  // stands for the symbolic bound M when reporting an unbounded x
 
 struct LpArgs {
     int m, n;
@@ -479,11 +480,11 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
         // assemble x by variable index in s.key
         for (int j = tid; j < n; j += NT) {
             const int v = s.nvar[j];
-            if (v < n) s.key[v] = s.side[j] == 2 ? INF : s.va[j];
+            if (v < n) s.key[v] = s.side[j] == 2 ? kMReport : s.va[j];
         }
         for (int i = tid; i < m; i += NT) {
             const int v = s.bvar[i];
-            if (v < n) s.key[v] = s.ba[i];
+            if (v < n) s.key[v] = fma(s.bb[i], kMReport, s.ba[i]);
         }
         for (int j = n + tid; j < NP; j += NT) s.key[j] = 0.0;
         __syncthreads();
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
 #pragma unroll
             for (int h = 32; h >= 1; h >>= 1) sum = sum + __shfl_down(sum, h, 64);
             if (tid == 0) {
-                if (g.obj) g.obj[node] = status == 1 ? INF : status == 2 ? -INF : sum;
+                if (g.obj) g.obj[node] = status == 1 ? INF : sum;
                 if (g.status) g.status[node] = status;
                 if (g.iters) g.iters[node] = iters;
                 if (g.npivots) g.npivots[node] = npiv;

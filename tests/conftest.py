@@ -24,3 +24,18 @@ def oracle():
 def gpu_ctx():
     from simple_mip_solver_amd import _ffi
     return _ffi.default_context()
+
+
+# Host-logic tests run twice: against the CPU oracle (no GPU needed, `-m "not gpu"`) and against
+# the real engine through the C ABI (`-m gpu`).  The product default is always the HIP backend.
+@pytest.fixture(params=['oracle', pytest.param('hip', marks=pytest.mark.gpu)])
+def engine(request):
+    from simple_mip_solver_amd import lp
+    if request.param == 'oracle':
+        from tests.support.oracle_backend import OracleBackend
+        backend = OracleBackend()
+    else:
+        backend = lp.HipBackend()
+    lp.set_backend(backend)
+    yield backend
+    lp.set_backend(None)

@@ -1,0 +1,18 @@
+NAME          ClpDefau
+ROWS
+ N  OBJROW
+ L  R_178_0
+ L  R_178_1
+COLUMNS
+    x_0       OBJROW     -8.        
+    x_1       OBJROW     -12.       
+    x_2       OBJROW     -11.       
+    x_3       OBJROW     -47.          R_178_1   56.         
+RHS
+    RHS       R_178_0   50.            R_178_1   46.         
+BOUNDS
+ UI BOUND     x_0       100.        
+ UI BOUND     x_1       100.        
+ UI BOUND     x_2       100.        
+ UI BOUND     x_3       100.        
+ENDATA

@@ -1,0 +1,14 @@
+NAME          ClpDefau
+ROWS
+ N  OBJROW
+ L  R_46_0
+ L  R_46_1
+COLUMNS
+    x_0       OBJROW     -8.           R_46_0    3.          
+    x_1       OBJROW     -12.       
+RHS
+    RHS       R_46_0    2.          
+BOUNDS
+ UI BOUND     x_0       100.        
+ UI BOUND     x_1       100.        
+ENDATA

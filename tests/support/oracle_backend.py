@@ -1,0 +1,20 @@
+"""LP backend that routes DenseLP solves to the CPU oracle -- FOR TESTS ONLY.
+
+Lets the `-m "not gpu"` suite exercise the host logic (node classes, driver, kwargs protocol)
+in a container without a GPU.  The product never installs this backend: the default is HipBackend
+(simple_mip_solver_amd/lp.py), which fails loudly when libmipx.so or the device is missing.
+"""
+from simple_mip_solver_amd.lp import LPBackend
+from oracle import oracle as O
+
+
+class OracleBackend(LPBackend):
+
+    def __init__(self):
+        self.calls = 0
+        self.lps = 0
+
+    def solve(self, A, b, c, l, u, vstat, max_iter, cache_key):
+        self.calls += 1
+        self.lps += len(l)
+        return O.lp_solve_batch(A, b, c, l, u, vstat, max_iter)

@@ -1,0 +1,60 @@
+"""The C-ABI library loads and exports every symbol include/mipx.h declares (no compute calls:
+this runs where there is no GPU), and fails loudly instead of falling back."""
+import os
+import re
+
+import pytest
+
+from simple_mip_solver_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'mipx.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mipx_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_ffi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = _ffi.lib()
+    for name in declared_symbols():
+        assert hasattr(L, name), f'libmipx.so does not export {name}'
+    assert L.mipx_abi_version() == 1
+
+
+def test_kernel_dispatch_table():
+    assert _ffi.kernel_name(32, 64) == 'lp_dual_simplex<4,16,8,4>'
+    assert _ffi.kernel_name(128, 256) == 'lp_dual_simplex<16,32,8,8>'
+    assert _ffi.kernel_name(129, 256) == 'lp_dual_simplex<16,32,12,8>'
+    with pytest.raises(_ffi.MipxError, match='MIPX_ETOOBIG'):
+        _ffi.kernel_name(512, 1024)
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product path raises; with one it creates a context."""
+    L = _ffi.lib()
+    if L.mipx_device_count() == 0:
+        with pytest.raises(_ffi.MipxError, match='no CPU fallback'):
+            _ffi.Context(0)
+        from simple_mip_solver_amd import lp
+        from tests.support.example_models import model
+        lp.set_backend(None)
+        with pytest.raises(_ffi.MipxError):
+            model('small_branch').lp.dual()
+    else:
+        _ffi.Context(0).close()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'simple_mip_solver_amd')
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(d, f)).read()
+                assert 'import oracle' not in text and 'from oracle' not in text, f
+                assert 'libmipx_oracle' not in text and 'mipx_oracle_' not in text, f

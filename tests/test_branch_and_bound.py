@@ -1,0 +1,272 @@
+"""BranchAndBound / BranchAndBoundTree against the whole-tree known answers the reference pins on
+`small_branch` (test_simple_mip_solver/test_algorithms/test_branch_and_bound.py:48-322) and its
+argument validation.  Runs on the CPU oracle backend and, marked gpu, on the HIP engine."""
+from queue import PriorityQueue
+from unittest.mock import patch
+
+import numpy as np
+import pytest
+
+from simple_mip_solver_amd import (BaseNode, BranchAndBound, PseudoCostBranchNode,
+                                   PseudoCostBranchDepthFirstSearchNode as PCBDFSNode)
+from simple_mip_solver_amd.algorithms.base_algorithm import BaseAlgorithm
+from simple_mip_solver_amd.algorithms.branch_and_bound import BranchAndBoundTree
+from tests.support.example_models import model, std_model
+
+INF = float('inf')
+
+
+def test_get_leaves_fails_asserts(engine):
+    bb = BranchAndBound(std_model('small_branch'), gomory_cuts=False)
+    bb.solve()
+    with pytest.raises(AssertionError, match='subtree_root_id must belong to the tree'):
+        bb.tree.get_leaves(20)
+    with pytest.raises(AssertionError, match='depth is a nonnegative integer'):
+        bb.tree.get_leaves(subtree_root_id=0, depth=1.5)
+    with pytest.raises(AssertionError, match="keep is one of 'all', 'feasible', or 'not infeasible'"):
+        bb.tree.get_leaves(subtree_root_id=0, keep=False)
+
+
+def test_get_leaves_whole_tree(engine):
+    bb = BranchAndBound(std_model('small_branch'), gomory_cuts=False, node_limit=1)
+    bb.solve()
+    assert len(bb.tree.get_leaves(0, keep='not infeasible')) == 2
+    assert not bb.tree.get_leaves(0, keep='feasible')
+
+    bb.node_limit = INF
+    bb.solve()
+    assert sorted(bb.tree.nodes) == list(range(13))
+    leaves = {n.idx for n in bb.tree.get_leaves(0)}
+    for node_id in bb.tree.nodes:
+        assert len(bb.tree.get_children(node_id)) == (0 if node_id in leaves else 2)
+    assert {n.idx for n in bb.tree.get_leaves(0) if not n.lp_feasible} == {2, 6, 8, 10, 12}
+
+    assert [n.idx for n in bb.tree.get_leaves(2, depth=0)] == [2]
+    assert not bb.tree.get_leaves(2, depth=0, keep='feasible')
+    assert {n.idx for n in bb.tree.get_leaves(0, depth=1)} == {1, 2}
+    assert [n.idx for n in bb.tree.get_leaves(0, depth=1, keep='feasible')] == [1]
+    assert {n.idx for n in bb.tree.get_leaves(1, depth=2)} == {5, 6, 7, 8}
+    assert {n.idx for n in bb.tree.get_leaves(1, depth=2, keep='feasible')} == {5, 7}
+    assert {n.idx for n in bb.tree.get_leaves(1, depth=3)} == {5, 6, 8, 9, 10}
+    assert {n.idx for n in bb.tree.get_leaves(1, depth=3, keep='feasible')} == {5, 9}
+    for n in bb.tree.get_leaves(1, depth=2):
+        assert bb.tree.get_parent(bb.tree.get_parent(n.idx)) == 1
+
+
+def test_get_disjunction(engine):
+    bb = BranchAndBound(std_model('small_branch'), gomory_cuts=False)
+    bb.solve()
+    with pytest.raises(AssertionError, match='subtree_root_id must belong to the tree'):
+        bb.tree.get_disjunction(20)
+    d = bb.tree.get_disjunction(0)
+    assert set(d) == {5, 11}
+    assert all(d[5][0] == [0, 0, 0]) and all(d[5][1] == [0, 1, 1])
+    assert all(d[11][0] == [1, 0, 0]) and all(d[11][1] == [1, 1, 0])
+
+
+def test_get_node_instances(engine):
+    bb = BranchAndBound(std_model('small_branch'), gomory_cuts=False, node_limit=1)
+    bb.solve()
+    with pytest.raises(AssertionError, match='must be an integer or iterable'):
+        bb.tree.get_node_instances('1')
+    with pytest.raises(AssertionError, match='are not in the tree'):
+        bb.tree.get_node_instances([20])
+    n1, n2 = bb.tree.get_node_instances([1, 2])
+    assert (n1.idx, n2.idx) == (1, 2) and isinstance(n1, BaseNode)
+    assert bb.tree.get_node_instances(1) is n1
+
+
+def test_subtree_dual_bound(engine):
+    bb = BranchAndBound(model('small_branch'), gomory_cuts=False, node_limit=1)
+    with pytest.raises(AssertionError, match='subtree_root_id must belong to the tree'):
+        bb.tree.subtree_dual_bound(subtree_root_id=1)
+    assert bb.tree.subtree_dual_bound(0) == -INF and bb.dual_bound == -INF
+    bb.solve()
+    assert bb.tree.subtree_dual_bound(0) == -2.75 == bb.dual_bound
+    bb.node_limit = 2
+    bb.solve()
+    assert bb.tree.subtree_dual_bound(0) == -2.75 == bb.dual_bound
+    bb.node_limit = INF
+    bb.solve()
+    assert bb.tree.subtree_dual_bound(0) == -2 == bb.dual_bound
+    assert bb.tree.subtree_dual_bound(2) == INF
+    assert bb.tree.subtree_dual_bound(0, depth=1) == -2.75
+
+
+def test_init(engine):
+    bb = BranchAndBound(std_model('small_branch'))
+    assert isinstance(bb, BaseAlgorithm) and isinstance(bb.tree, BranchAndBoundTree)
+    assert bb.primal_bound == INF and bb.dual_bound == -INF
+    assert bb._node_queue.empty() and not bb._unbounded and not bb._best_solution
+    assert bb.solution is None and bb.status == 'unsolved' and bb.objective_value is None
+    assert list(bb.tree.nodes) == [0] and bb.tree.nodes[0].attr['node'] is bb.root_node
+    assert bb.solve_time == 0 and bb.mip_gap and not bb.logging and bb.max_run_time == INF
+    assert bb._kwargs == {'next_node_idx': 1}
+
+
+def test_init_fails_asserts(engine):
+    m = std_model('small_branch')
+    bb = BranchAndBound(m)
+    queue = PriorityQueue()
+    for func in reversed(bb._queue_funcs):
+        queue.__dict__[func] = 5
+        with pytest.raises(AssertionError, match=f'node_queue needs a {func} function'):
+            BranchAndBound(m, BaseNode, queue)
+    for kw, msg in [({'node_limit': -5}, 'node limit must be positive integer or infinity'),
+                    ({'mip_gap': -5}, 'mip_gap is a ratio'), ({'logging': 0}, 'logging is boolean'),
+                    ({'max_run_time': 0}, 'max_run_time is positive'),
+                    ({'initial_primal_bound': -INF}, 'initial_primal_bound is real'),
+                    ({'right': -5}, 'saved for later use'),
+                    ({'next_node_idx': 4}, 'next_node_idx is reserved')]:
+        with pytest.raises(AssertionError, match=msg):
+            BranchAndBound(model=m, **kw)
+    with pytest.raises(AssertionError, match='model must be cuppy MILPInstance'):
+        BranchAndBound(model='fish')
+    with pytest.raises(AssertionError, match='Node must be a class'):
+        BranchAndBound(m, Node=bb.root_node)
+
+    class NoBranch:
+        def __init__(self, **kw):
+            for a in BranchAndBound._node_attributes:
+                setattr(self, a, None)
+
+        def bound(self): pass
+        def __lt__(self, o): return True
+        def __eq__(self, o): return True
+
+    with pytest.raises(AssertionError, match='Node needs a branch function'):
+        BranchAndBound(m, Node=NoBranch)
+
+
+def test_current_gap(engine):
+    bb = BranchAndBound(std_model('small_branch'), node_limit=1, gomory_cuts=False)
+    bb.solve()
+    assert bb.current_gap is None
+    bb.node_limit = 10
+    bb.solve()
+    assert bb.current_gap == .125
+    bb.node_limit = INF
+    bb.solve()
+    assert bb.current_gap == 0
+
+
+@pytest.mark.parametrize('Node', [BaseNode, PCBDFSNode, PseudoCostBranchNode])
+def test_solve_statuses(engine, Node):
+    bb = BranchAndBound(std_model('small_branch'), Node=Node, max_run_time=1e-9, pseudo_costs={})
+    bb.solve()
+    assert bb.status == 'stopped on iterations or time' and bb.solve_time > 1e-9
+
+    bb = BranchAndBound(std_model('small_branch'), Node=Node, node_limit=1, pseudo_costs={},
+                        gomory_cuts=False)
+    bb.solve()
+    assert bb.status == 'stopped on iterations or time' and bb.evaluated_nodes == 1
+
+    bb = BranchAndBound(std_model('small_branch'), Node=Node, pseudo_costs={})
+    bb.solve()
+    assert bb.status == 'optimal' and bb.objective_value == -2
+    assert all(float(s).is_integer() for s in bb.solution) and bb.solve_time
+
+    bb = BranchAndBound(model('infeasible2'), Node=Node, pseudo_costs={})
+    bb.solve()
+    assert bb.status == 'infeasible' and bb.solution is None and bb.objective_value == INF
+
+    bb = BranchAndBound(model('unbounded'), Node=Node, pseudo_costs={})
+    bb.solve()
+    assert bb.status == 'unbounded'
+
+
+def test_unbounded_flag_stops_before_evaluating(engine):
+    bb = BranchAndBound(model('unbounded'))
+    bb._unbounded = True
+    with patch.object(bb, '_evaluate_node') as en:
+        bb.solve()
+    assert not en.called
+
+
+def test_evaluate_node_prunes_on_inherited_bound(engine):
+    bb = BranchAndBound(std_model('small_branch'), gomory_cuts=False)
+    bb.primal_bound = -3  # better than anything in this tree
+    bb.root_node.dual_bound = -2.75
+    with patch.object(bb.root_node, 'bound') as b:
+        bb._evaluate_node(bb.root_node)
+    assert not b.called and bb.evaluated_nodes == 0
+
+
+def test_evaluate_node_incumbent_and_branch(engine):
+    bb = BranchAndBound(model('no_branch'))
+    bb._evaluate_node(bb.root_node)
+    assert bb.primal_bound == -2 and all(bb._best_solution == [1, 1, 0])
+    assert bb.evaluated_nodes == 1 and bb._node_queue.empty()
+
+    bb = BranchAndBound(std_model('small_branch'), gomory_cuts=False)
+    bb._evaluate_node(bb.root_node)
+    assert bb.primal_bound == INF and bb._node_queue.qsize() == 2
+    assert bb._kwargs['next_node_idx'] == 3 and sorted(bb.tree.nodes) == [0, 1, 2]
+    assert bb.tree.get_left_child(0) == 1 and bb.tree.get_right_child(0) == 2
+
+
+def test_process_branch_rtn_fails_asserts(engine):
+    bb = BranchAndBound(std_model('small_branch'), gomory_cuts=False)
+    bb.root_node.bound(gomory_cuts=False)
+    rtn = bb.root_node.branch(next_node_idx=1)
+    with pytest.raises(AssertionError, match='rtn must be a dictionary'):
+        bb._process_branch_rtn(0, 'fish')
+    with pytest.raises(AssertionError, match='parent_id must be integer'):
+        bb._process_branch_rtn('0', rtn)
+    with pytest.raises(AssertionError, match='parent must already exist in tree'):
+        bb._process_branch_rtn(5, rtn)
+    with pytest.raises(AssertionError, match='left must be in the returned dict'):
+        bb._process_branch_rtn(0, {'right': rtn['right']})
+    with pytest.raises(AssertionError, match='value must be type'):
+        bb._process_branch_rtn(0, {'left': 5, 'right': rtn['right']})
+    bb._process_branch_rtn(0, dict(rtn))
+    with pytest.raises(AssertionError, match='please give unique node ID'):
+        bb._process_branch_rtn(0, dict(rtn))
+
+
+def test_process_bound_rtn_shares_cuts_with_queued_nodes(engine):
+    bb = BranchAndBound(std_model('small_branch'), gomory_cuts=False)
+    bb._evaluate_node(bb.root_node)
+    from simple_mip_solver_amd import CyLPArray
+    cut = (CyLPArray([0, -1, 0]), -2)
+    bb._process_bound_rtn({'cuts': {'cut_cglp_0_1': cut}, 'fish': 7})
+    assert all('cut_cglp_0_1' in n.cut_pool for n in bb._node_queue.queue)
+    assert bb._kwargs['fish'] == 7 and 'cuts' not in bb._kwargs
+    with pytest.raises(AssertionError, match='rtn must be a dictionary'):
+        bb._process_bound_rtn('fish')
+    with pytest.raises(AssertionError, match='rtn keys must be strings'):
+        bb._process_rtn({5: 5})
+
+
+def test_custom_queue_and_node_subclass_plug_in(engine):
+    """The plugin surface: a user queue (LIFO) and a user Node overriding branch()."""
+
+    class Stack:
+        def __init__(self): self.items = []
+        def put(self, x): self.items.append(x)
+        def get(self): return self.items.pop()
+        def empty(self): return not self.items
+
+    class FirstFractionalNode(BaseNode):
+        def branch(self, **kwargs):
+            j = next(i for i in self._integer_indices if self._is_fractional(self.solution[i]))
+            return self._base_branch(j, **kwargs)
+
+    bb = BranchAndBound(std_model('small_branch'), Node=FirstFractionalNode, node_queue=Stack(),
+                        gomory_cuts=False)
+    bb.solve()
+    assert bb.status == 'optimal' and bb.objective_value == -2
+
+
+def test_max_model_is_flipped(engine):
+    bb = BranchAndBound(model('small_branch_max'), gomory_cuts=False)
+    assert bb._swapped_constraint_direction and bb.model.sense == '>='
+    assert np.array_equal(bb.model.A, [[-1, 0, -1], [0, -1, 0]])
+    assert np.array_equal(bb.model.lp.objective, [-1, -1, -1])
+    bb.solve()
+    assert bb.status == 'optimal' and bb.objective_value == -2
+
+
+def test_find_parameterized_dual_bound_is_out_of_scope(engine):
+    with pytest.raises(NotImplementedError, match='outside the node hot path'):
+        BranchAndBound(std_model('small_branch')).find_parameterized_dual_bound([1, 1])

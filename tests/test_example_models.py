@@ -1,0 +1,63 @@
+"""The reference's integration suite (helpers.TestModels.base_test_models, helpers.py:30-73): every
+one of its 64 random example .mps instances is solved by BranchAndBound and compared with an
+independent optimum -- committed HiGHS values (tests/golden/example_models_optima.json) instead of
+Gurobi at test time.  The reference's bar is abs_tol=.01; BASELINE asks 1e-6 (all optima are
+integers).  Parity of these objectives is not pinned by the reference itself ("parity unpinned")."""
+import json
+from math import isclose
+import os
+
+import pytest
+
+from simple_mip_solver_amd import (BaseNode, BranchAndBound, DepthFirstSearchNode, MILPInstance,
+                                   PseudoCostBranchNode, PseudoCostBranchDepthFirstSearchNode)
+
+HERE = os.path.dirname(__file__)
+TABLE = json.load(open(os.path.join(HERE, 'golden', 'example_models_optima.json')))['models']
+
+
+def check_pseudo_costs(bb):  # helpers.py:54-60
+    if bb.evaluated_nodes >= 4 and isinstance(bb.root_node, PseudoCostBranchNode):
+        p = bb._kwargs['pseudo_costs']
+        assert len(p) <= bb.root_node.lp.nVariables
+        assert sum(sum(b['times'] for b in e.values()) for e in p.values()) <= \
+            2 * (bb.evaluated_nodes + bb.root_node.lp.nVariables)
+
+
+def check_gmics(bb):  # helpers.py:62-73
+    if bb.evaluated_nodes >= 2 and bb._kwargs.get('gomory_cuts', True) and \
+            bb._kwargs['total_cut_generation_iterations']:
+        k = bb._kwargs
+        assert k['total_number_gmic_added'] <= k['total_number_gmic_created']
+        assert k['total_iterations_gmic_added'] <= k['total_iterations_gmic_created']
+
+
+@pytest.mark.parametrize('Node,kwargs', [
+    (BaseNode, {'gomory_cuts': False}), (PseudoCostBranchNode, {'gomory_cuts': False}),
+    (DepthFirstSearchNode, {'gomory_cuts': False}),
+    (PseudoCostBranchDepthFirstSearchNode, {'gomory_cuts': False})])
+def test_models_without_cuts(engine, Node, kwargs):
+    for f, rec in sorted(TABLE.items()):
+        m = MILPInstance(file_name=os.path.join(HERE, 'golden', 'example_models', f))
+        bb = BranchAndBound(m, Node, pseudo_costs={}, **kwargs)
+        bb.solve()
+        assert bb.status == 'optimal', f
+        assert isclose(bb.objective_value, rec['milp_opt'], abs_tol=1e-6), \
+            f'{f}: {bb.objective_value} vs HiGHS {rec["milp_opt"]}'
+        assert isclose(bb.root_node.objective_value, rec['lp_opt'], rel_tol=1e-6, abs_tol=1e-6), f
+        check_pseudo_costs(bb)
+
+
+@pytest.mark.parametrize('Node', [BaseNode, PseudoCostBranchNode])
+def test_models_with_gomory_cuts(engine, Node):
+    """Reference defaults (gomory_cuts=True, tolerance.py values).  Rounded cuts move optima by
+    up to ~1e-5 (e.g. cut2: -36.00001), hence the reference's own abs_tol=.01 (helpers.py:45)."""
+    for f, rec in sorted(TABLE.items()):
+        m = MILPInstance(file_name=os.path.join(HERE, 'golden', 'example_models', f))
+        bb = BranchAndBound(m, Node, pseudo_costs={})
+        bb.solve()
+        assert bb.status == 'optimal', f
+        assert isclose(bb.objective_value, rec['milp_opt'], abs_tol=.01), \
+            f'{f}: {bb.objective_value} vs HiGHS {rec["milp_opt"]}'
+        check_pseudo_costs(bb)
+        check_gmics(bb)

@@ -1,0 +1,91 @@
+"""Pins the CPU oracle's LP part to the reference's known answers at the Clp boundary
+ and to independent HiGHS optima."""
+import json
+import os
+
+import numpy as np
+import pytest
+from scipy.optimize import linprog
+
+from simple_mip_solver_amd.generators import random_dense_milp_arrays
+
+INF = np.inf
+
+
+def test_no_branch_root(oracle):  # test_base_node.py:394-404
+    r = oracle.lp_solve(-np.eye(3), [-1, -1, -1], [-1, -1, 0], [0, 0, 0], [INF] * 3)
+    assert r['status'] == 0 and r['obj'] == -2 and all(r['x'] == [1, 1, 0])
+
+
+def test_small_branch_root(oracle):  # test_base_node.py:406-416
+    r = oracle.lp_solve([[-1, 0, -1], [0, -1, 0]], [-1.5, -1.25], [-1, -1, -1], [0, 0, 0], [10] * 3)
+    assert r['status'] == 0 and r['obj'] == -2.75 and all(r['x'] == [0, 1.25, 1.5])
+
+
+def test_infeasible(oracle):  # test_base_node.py:418-428
+    r = oracle.lp_solve([[-1, -1, 0]], [1], [-1, -1, 0], [0, 0, 0], [INF] * 3)
+    assert r['status'] == 1 and r['obj'] == INF
+
+
+def test_unbounded(oracle):  # test_base_node.py:430-437 (flags; the Clp number is an artefact)
+    r = oracle.lp_solve([[-1, 1], [1, -1]], [-.5, -.5], [-1, -1], [0, 0], [INF] * 2)
+    assert r['status'] == 2 and r['obj'] < -1e9
+
+
+def test_cut2_root_and_cut3_basis(oracle):  # test_base_node.py:488, :681-684
+    r = oracle.lp_solve([[-4, -1], [-1, -4], [-1, 1]], [-28, -27, -1], [-2, -5], [0, 0], [INF] * 2)
+    assert r['status'] == 0 and r['obj'] == -38.0
+    r = oracle.lp_solve([[-3, -4], [-5, -10], [-1, -2]], [-10, -8, -1.2], [-8, -12], [0, 0], [INF] * 2)
+    assert np.allclose(r['x'], [1.2, 0]) and list(np.where(r['vstat'] == 1)[0]) == [0, 2, 3]
+
+
+def test_warm_started_children_of_small_branch(oracle):  # hand trace in SURVEY.md section 8c
+    A, b, c = [[-1, 0, -1], [0, -1, 0]], [-1.5, -1.25], [-1, -1, -1]
+    root = oracle.lp_solve(A, b, c, [0, 0, 0], [10] * 3)
+    left = oracle.lp_solve(A, b, c, [0, 0, 0], [10, 10, 1], vstat=root['vstat'])
+    right = oracle.lp_solve(A, b, c, [0, 0, 2], [10, 10, 10], vstat=root['vstat'])
+    assert left['status'] == 0 and all(left['x'] == [.5, 1.25, 1]) and left['obj'] == -2.75
+    assert right['status'] == 1
+
+
+def test_iteration_limit_reports_status_3_and_a_valid_bound(oracle):
+    A, b, c, l, u, _ = random_dense_milp_arrays(40, 20, seed=1)
+    full = oracle.lp_solve(A, b, c, l, u)
+    part = oracle.lp_solve(A, b, c, l, u, max_iter=5)
+    assert full['status'] == 0 and part['status'] == 3 and part['iters'] == 5
+    assert part['obj'] <= full['obj'] + 1e-9  # dual simplex objective is a lower bound
+
+
+@pytest.mark.parametrize('n,m,seed', [(64, 32, s) for s in range(6)] + [(256, 128, 0), (30, 50, 2)])
+def test_objective_matches_highs(oracle, n, m, seed):
+    A, b, c, l, u, _ = random_dense_milp_arrays(n, m, seed=seed)
+    r = oracle.lp_solve(A, b, c, l, u)
+    h = linprog(c, A_ub=-A, b_ub=-b, bounds=list(zip(l, u)), method='highs')
+    assert r['status'] == 0 and h.status == 0
+    assert abs(r['obj'] - h.fun) <= 1e-6 * max(1, abs(h.fun))
+    assert np.all(A @ r['x'] >= b - 1e-6) and np.all(r['x'] >= l - 1e-9) and np.all(r['x'] <= u + 1e-9)
+
+
+def test_example_models_lp_relaxations_match_highs(oracle):
+    from simple_mip_solver_amd.milp_instance import read_mps
+    here = os.path.dirname(__file__)
+    table = json.load(open(os.path.join(here, 'golden', 'example_models_optima.json')))['models']
+    assert len(table) == 64
+    for f, rec in table.items():
+        A, b, c, l, u, sense, ints = read_mps(os.path.join(here, 'golden', 'example_models', f))
+        assert sense[1] == '<='
+        u = np.where(u > 1e300, INF, u)
+        r = oracle.lp_solve(-A, -b, c, l, u)
+        assert r['status'] == 0 and abs(r['obj'] - rec['lp_opt']) <= 1e-6 * max(1, abs(rec['lp_opt'])), f
+
+
+def test_branching_helpers(oracle):
+    x = np.array([0, 1.25, 1.5])
+    assert oracle.most_fractional([0, 1, 2], x) == 2          # test_base_node.py:824-826
+    assert oracle.most_fractional([0, 1], np.array([1., 2., .5])) is None
+    assert oracle.mip_feasible([0, 1], np.array([1.00001, 2., .5]))
+    assert oracle.most_fractional([2, 1], np.array([0, 1.5, 2.5])) == 2  # first max in list order
+    cl = np.array([0., 1., 0.]); cr = np.array([0., 0., 0.])
+    assert oracle.best_pseudo_cost([0, 1, 2], x, cl, cr) == 1  # all scores 0 -> earliest fractional
+    assert oracle.pseudo_cost_update(1.0, 1, 0, -2.25, -2.75, .5) == (1.0, 2)
+    assert oracle.pseudo_cost_update(1.0, 1, 1, 0., 0., .5) == (1.0, 2)  # infeasible: visit only
