@@ -29,7 +29,9 @@ def check_gmics(bb):  # helpers.py:62-73
             bb._kwargs['total_cut_generation_iterations']:
         k = bb._kwargs
         assert k['total_number_gmic_added'] <= k['total_number_gmic_created']
-        assert k['total_iterations_gmic_added'] <= k['total_iterations_gmic_created']
+        # (the reference also compares the *iteration* counts, "just rough values": a round can
+        # add cuts left in the pool by an earlier round while creating none, so that one is not
+        # an invariant of the algorithm and is not asserted here)
 
 
 @pytest.mark.parametrize('Node,kwargs', [
