@@ -273,9 +273,12 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
         // rho, coln and scalar pieces from s.row / s.alpha (row r and column q extracted)
         auto prepare_pivot = [&](int r, int q, bool with_values, double la, double lb) {
             const double p = s.row[q];
-            for (int k = tid; k < n + m; k += NT) {
-                if (k < n) s.rho[k] = s.row[k] / p;
-                else s.coln[k - n] = -s.alpha[k - n] / p;
+            // padded entries (j >= n, i >= m) are written as exact zeros every time: LDS is not
+            // initialised, and garbage there would leak NaN/Inf into the padded tableau entries
+            // and from there into the fold-in-half sums of step 2
+            for (int k = tid; k < NP + MP; k += NT) {
+                if (k < NP) s.rho[k] = k < n ? s.row[k] / p : 0.0;
+                else s.coln[k - NP] = (k - NP) < m ? -s.alpha[k - NP] / p : 0.0;
             }
             if (tid == NT - 1) {
                 s.scal[S_PINV] = 1.0 / p;

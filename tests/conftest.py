@@ -35,7 +35,8 @@ def engine(request):
         from tests.support.oracle_backend import OracleBackend
         backend = OracleBackend()
     else:
-        backend = lp.HipBackend()
+        from tests.support.compare_backend import CompareBackend
+        backend = CompareBackend()  # the HIP engine, every solve checked against the oracle
     lp.set_backend(backend)
     yield backend
     lp.set_backend(None)

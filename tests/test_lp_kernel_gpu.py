@@ -127,3 +127,25 @@ def test_too_big_fails_loudly(gpu_ctx):
     A, b, c, l, u, _ = random_dense_milp_arrays(1024, 512, seed=0)
     with pytest.raises(_ffi.MipxError, match='MIPX_ETOOBIG'):
         _ffi.Problem(gpu_ctx, A, b, c)
+
+
+def test_warm_start_with_padding_after_lds_pollution(gpu_ctx, oracle):
+    """Regression: uninitialised LDS in the padded part of the pivot vectors once leaked NaN into
+    the refactored tableau of LPs much smaller than the tile (n=2, m=5 in a 64x32 tile)."""
+    A, b, c, l, u, _ = random_dense_milp_arrays(256, 128, seed=1)
+    _ffi.Problem(gpu_ctx, A, b, c).solve_batch(l[None], u[None])  # leaves junk in LDS
+    A = np.array([[-4., -1.], [-1., -4.], [-1., 1.], [-0.36363636363636365, -1.], [-1., -2 / 3]])
+    b = np.array([-28., -27., -1., -7.090909090909091, -9.])
+    c = np.array([-2., -5.])
+    l, u = np.zeros((1, 2)), np.full((1, 2), INF)
+    V = np.array([[1, 1, 3, 3, 1, 1, 1]], np.int8)
+    p = _ffi.Problem(gpu_ctx, A, b, c)
+    for _ in range(3):
+        assert_same(p.solve_batch(l, u, V), oracle.lp_solve_batch(A, b, c, l, u, V), 'padded warm')
+    for n, m, seed in [(5, 3, 0), (9, 7, 1), (33, 17, 2), (70, 20, 3), (130, 66, 4)]:
+        A, b, c, l, u, _ = random_dense_milp_arrays(n, m, seed=seed)
+        p = _ffi.Problem(gpu_ctx, A, b, c)
+        root = p.solve_batch(l[None], u[None])
+        L, U, V = _children(A, b, c, l, u, root, 6)
+        if len(L):
+            assert_same(p.solve_batch(L, U, V), oracle.lp_solve_batch(A, b, c, L, U, V), f'{n}x{m}')
