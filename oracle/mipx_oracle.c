@@ -36,7 +36,8 @@
  *      two-component numbers a + b*M; beta = beta0 - T v_N with a fold-in-half summation tree.
  *   3. dual simplex: leaving row = largest bound violation (M-level beats real level, ties ->
  *      lowest variable index); Harris two-pass ratio test (ties -> lowest variable index);
- *      rank-1 tableau update with explicit fma.
+ *      rank-1 tableau update with explicit fma; the pivot row is scaled by the reciprocal
+ *      1/p (one division per pivot), as the kernel does.
  *   4. status 0 optimal / 1 primal infeasible / 2 unbounded (optimum depends on M) /
  *      3 iteration limit -- the Clp codes the reference reads (base_node.py:274-275,
  *      pseudo_cost.py:86).
@@ -88,24 +89,24 @@ static void tab_pivot(tab_t *t, int r, int q) {
     double *T = t->T;
     const double p = T[(size_t)r * n + q];
     const double pinv = 1.0 / p;
-    /* rho_j = T_rj / p, alpha_i = T_iq */
+    /* rho_j = T_rj * (1/p), alpha_i = T_iq */
     double *rho = (double *)malloc(sizeof(double) * (size_t)(n + 1));
-    for (int j = 0; j < n; j++) rho[j] = T[(size_t)r * n + j] / p;
-    rho[n] = t->beta0[r] / p;
+    for (int j = 0; j < n; j++) rho[j] = T[(size_t)r * n + j] * pinv;
+    rho[n] = t->beta0[r] * pinv;
     for (int i = 0; i < m; i++) {
         if (i == r) continue;
         const double a = T[(size_t)i * n + q];
         double *Ti = T + (size_t)i * n;
         for (int j = 0; j < n; j++)
             if (j != q) Ti[j] = fma(-a, rho[j], Ti[j]);
-        Ti[q] = -a / p;
+        Ti[q] = -a * pinv;
         t->beta0[i] = fma(-a, rho[n], t->beta0[i]);
     }
     {
         const double a = t->d[q];
         for (int j = 0; j < n; j++)
             if (j != q) t->d[j] = fma(-a, rho[j], t->d[j]);
-        t->d[q] = -a / p;
+        t->d[q] = -a * pinv;
     }
     for (int j = 0; j < n; j++) T[(size_t)r * n + j] = rho[j];
     T[(size_t)r * n + q] = pinv;
@@ -285,7 +286,8 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
             else if (!isinf(up)) { la = up; lb = 0.0; newside = 1; }
             else { la = 0.0; lb = 1.0; newside = 2; }
             const double p = Tr[q];
-            const double ta = (ba[r] - la) / p, tb = (bb[r] - lb) / p;
+            const double pinv = 1.0 / p;
+            const double ta = (ba[r] - la) * pinv, tb = (bb[r] - lb) * pinv;
             for (int i = 0; i < m; i++) {
                 if (i == r) continue;
                 double al = t.T[(size_t)i * n + q];

@@ -88,10 +88,8 @@ __device__ __forceinline__ Best wave_best(Best v) {
 
 template <int MP, int NP>
 struct Smem {
-    double row[NP];    // extracted pivot row
-    double rho[NP];    // row / p
-    double alpha[MP];  // extracted pivot column
-    double coln[MP];   // -alpha / p
+    double row[NP];    // extracted pivot row T[r][.]
+    double alpha[MP];  // extracted pivot column T[.][q]
     double beta0[MP];
     double ba[MP];
     double bb[MP];
@@ -103,15 +101,14 @@ struct Smem {
     double key[NP];    // scratch: ratio keys / x assembly
     double aabs[NP];
     double dje[NP];
-    double scal[16];
     int bvar[MP];
     int nvar[NP];
     int side[NP];      // 0 lower, 1 upper, 2 fake upper
+    int wlist[NP];     // structurals the warm start wants basic, ascending
+    int nw;
     int8_t wantb[NP + MP];
     int8_t atup[NP + MP];
 };
-
-enum { S_RHON = 0, S_TA, S_TB, S_NBA, S_NBB, S_DQ, S_DQN, S_PINV, S_LA, S_LB };
 
 template <int TBI, int TBJ, int R, int C>
 __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
@@ -130,7 +127,11 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
     const int nv = n + m;
     const double INF = __builtin_huge_val();
 
-    for (int node = blockIdx.x; node < g.batch; node += gridDim.x) {
+    // one workgroup per node LP (no grid-stride loop: a loop here makes the compiler hoist every
+    // per-element predicate and address of the setup across the whole solve -> register spills)
+    const int node = blockIdx.x;
+    if (node >= g.batch) return;
+    {
         double T[R][C];
         const double *lk = g.l + (size_t)node * n;
         const double *uk = g.u + (size_t)node * n;
@@ -140,18 +141,21 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
 #pragma unroll
         for (int ii = 0; ii < R; ii++) {
             const int i = bi + TBI * ii;
+            const double *arow = g.A + (size_t)(i < m ? i : 0) * n + bj;  // one base per row
 #pragma unroll
             for (int jj = 0; jj < C; jj++) {
                 const int j = bj + TBJ * jj;
-                T[ii][jj] = (i < m && j < n) ? -g.A[(size_t)i * n + j] : 0.0;
+                T[ii][jj] = (i < m && j < n) ? -arow[TBJ * jj] : 0.0;
             }
         }
+#pragma unroll 1
         for (int i = tid; i < MP; i += NT) {
             s.beta0[i] = i < m ? -g.b[i] : 0.0;
             s.bvar[i] = i < m ? n + i : -1;
             s.ba[i] = 0.0;
             s.bb[i] = 0.0;
         }
+#pragma unroll 1
         for (int j = tid; j < NP; j += NT) {
             s.d[j] = j < n ? g.c[j] : 0.0;
             s.nvar[j] = j < n ? j : -1;
@@ -161,152 +165,55 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
             s.va[j] = 0.0;
             s.vb[j] = 0.0;
         }
+#pragma unroll 1
         for (int v = tid; v < NP + MP; v += NT) {
             int8_t st = (vin && v < nv) ? vin[v] : (int8_t)0;
             s.wantb[v] = st == 1;
             s.atup[v] = st == 2;
         }
         __syncthreads();
+        if (tid < 64) {  // compact list of structurals to pivot in (ascending)
+            int cnt = 0;
+            for (int base = 0; base < n; base += 64) {
+                const int j = base + lane;
+                const bool w = j < n && s.wantb[j];
+                const unsigned long long mask = __ballot(w);
+                if (w) s.wlist[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+                cnt += __popcll(mask);
+            }
+            if (lane == 0) s.nw = cnt;
+        }
+        __syncthreads();
+        const int nw = __builtin_amdgcn_readfirstlane(s.nw);
 
-        auto vlo = [&](int v) -> double { return v < n ? s.lo[v] : 0.0; };
-        auto vup = [&](int v) -> double { return v < n ? s.up[v] : INF; };
+        int npiv = 0, iters = 0, status = -1;
+        int phase = vin ? 0 : 1;  // 0 refactor, 1 value initialisation, 2 dual simplex
+        int w = 0;
+        const int cap = 100 * (m + n) + 1000;
 
-        auto extract_col = [&](int q) {  // s.alpha[i] = T[i][q]
-            const int qb = q % TBJ, ql = q / TBJ;
-            if (bj == qb) {
-#pragma unroll
-                for (int jj = 0; jj < C; jj++) {
-                    if (jj == ql) {
-#pragma unroll
-                        for (int ii = 0; ii < R; ii++) s.alpha[bi + TBI * ii] = T[ii][jj];
-                    }
-                }
-            }
-        };
-        auto extract_row = [&](int r) {  // s.row[j] = T[r][j]
-            const int rb = r % TBI, rl = r / TBI;
-            if (bi == rb) {
-#pragma unroll
-                for (int ii = 0; ii < R; ii++) {
-                    if (ii == rl) {
-#pragma unroll
-                        for (int jj = 0; jj < C; jj++) s.row[bj + TBJ * jj] = T[ii][jj];
-                    }
-                }
-            }
-        };
-        // rank-1 update of the register tableau + borders, given s.alpha, s.rho, s.coln, s.scal
-        auto apply_pivot = [&](int r, int q, bool with_values, int newside) {
-            const int rb = r % TBI, rl = r / TBI;
-            const int qb = q % TBJ, ql = q / TBJ;
-            double al[R], rh[C];
-#pragma unroll
-            for (int ii = 0; ii < R; ii++) al[ii] = s.alpha[bi + TBI * ii];
-#pragma unroll
-            for (int jj = 0; jj < C; jj++) rh[jj] = s.rho[bj + TBJ * jj];
-#pragma unroll
-            for (int ii = 0; ii < R; ii++) {
-                const double a = (bi == rb && ii == rl) ? 0.0 : al[ii];
-#pragma unroll
-                for (int jj = 0; jj < C; jj++) {
-                    const double h = (bj == qb && jj == ql) ? 0.0 : rh[jj];
-                    T[ii][jj] = fma(-a, h, T[ii][jj]);
-                }
-            }
-            // column q <- -alpha/p (rows != r)
-            if (bj == qb) {
-#pragma unroll
-                for (int jj = 0; jj < C; jj++) {
-                    if (jj == ql) {
-#pragma unroll
-                        for (int ii = 0; ii < R; ii++) T[ii][jj] = s.coln[bi + TBI * ii];
-                    }
-                }
-            }
-            // row r <- rho (and 1/p at column q)
-            if (bi == rb) {
-                const double pinv = s.scal[S_PINV];
-#pragma unroll
-                for (int ii = 0; ii < R; ii++) {
-                    if (ii == rl) {
+        for (;;) {
+            int r = 0, q = 0, sigma = 1, newside = 0;
+            double la = 0.0, lb = 0.0;
+
+            if (phase == 0) {
+                // ---- 1. refactor: pivot the next wanted structural into the basis -----------
+                if (w >= nw) { phase = 1; continue; }
+                q = __builtin_amdgcn_readfirstlane(s.wlist[w]);
+                w++;
+                {   // column q -> s.alpha
+                    const int qb = q % TBJ, ql = q / TBJ;
+                    if (bj == qb) {
 #pragma unroll
                         for (int jj = 0; jj < C; jj++)
-                            T[ii][jj] = (bj == qb && jj == ql) ? pinv : rh[jj];
+                            if (jj == ql) {
+#pragma unroll
+                                for (int ii = 0; ii < R; ii++) s.alpha[bi + TBI * ii] = T[ii][jj];
+                            }
                     }
                 }
-            }
-            // borders
-            const double rhon = s.scal[S_RHON];
-            const double ta = s.scal[S_TA], tb = s.scal[S_TB];
-            for (int i = tid; i < m; i += NT) {
-                const double a = s.alpha[i];
-                if (i == r) {
-                    s.beta0[i] = rhon;
-                    if (with_values) { s.ba[i] = s.scal[S_NBA]; s.bb[i] = s.scal[S_NBB]; }
-                } else {
-                    s.beta0[i] = fma(-a, rhon, s.beta0[i]);
-                    if (with_values) {
-                        s.ba[i] = fma(-a, ta, s.ba[i]);
-                        s.bb[i] = fma(-a, tb, s.bb[i]);
-                    }
-                }
-            }
-            const double dq = s.scal[S_DQ];
-            for (int j = tid; j < n; j += NT) {
-                if (j == q) {
-                    s.d[j] = s.scal[S_DQN];
-                    if (with_values) {
-                        s.side[j] = newside;
-                        s.va[j] = s.scal[S_LA];
-                        s.vb[j] = s.scal[S_LB];
-                    }
-                } else {
-                    s.d[j] = fma(-dq, s.rho[j], s.d[j]);
-                }
-            }
-            if (tid == NT - 1) {
-                const int tmp = s.bvar[r];
-                s.bvar[r] = s.nvar[q];
-                s.nvar[q] = tmp;
-            }
-        };
-        // rho, coln and scalar pieces from s.row / s.alpha (row r and column q extracted)
-        auto prepare_pivot = [&](int r, int q, bool with_values, double la, double lb) {
-            const double p = s.row[q];
-            // padded entries (j >= n, i >= m) are written as exact zeros every time: LDS is not
-            // initialised, and garbage there would leak NaN/Inf into the padded tableau entries
-            // and from there into the fold-in-half sums of step 2
-            for (int k = tid; k < NP + MP; k += NT) {
-                if (k < NP) s.rho[k] = k < n ? s.row[k] / p : 0.0;
-                else s.coln[k - NP] = (k - NP) < m ? -s.alpha[k - NP] / p : 0.0;
-            }
-            if (tid == NT - 1) {
-                s.scal[S_PINV] = 1.0 / p;
-                s.scal[S_RHON] = s.beta0[r] / p;
-                const double dq = s.d[q];
-                s.scal[S_DQ] = dq;
-                s.scal[S_DQN] = -dq / p;
-                if (with_values) {
-                    const double ta = (s.ba[r] - la) / p, tb = (s.bb[r] - lb) / p;
-                    s.scal[S_TA] = ta;
-                    s.scal[S_TB] = tb;
-                    s.scal[S_NBA] = s.va[q] + ta;
-                    s.scal[S_NBB] = s.vb[q] + tb;
-                    s.scal[S_LA] = la;
-                    s.scal[S_LB] = lb;
-                }
-            }
-        };
-
-        int npiv = 0;
-
-        // ---- 1. refactor to the warm-start basis -------------------------------------------
-        if (vin) {
-            for (int q = 0; q < n; q++) {
-                if (!__builtin_amdgcn_readfirstlane((int)s.wantb[q])) continue;  // uniform
-                extract_col(q);
                 __syncthreads();
                 Best best{-1, 0.0, 0, -1}, fb{-1, 0.0, 0, -1};
+#pragma unroll 1
                 for (int i = lane; i < m; i += 64) {
                     const int bv = s.bvar[i];
                     const double a = fabs(s.alpha[i]);
@@ -317,166 +224,248 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                 }
                 best = wave_best(best);
                 if (__builtin_amdgcn_readfirstlane(best.hi) < 0) best = wave_best(fb);
-                const int r = __builtin_amdgcn_readfirstlane(best.idx);
-                if (r < 0) { __syncthreads(); continue; }
-                extract_row(r);
-                __syncthreads();
-                prepare_pivot(r, q, false, 0.0, 0.0);
-                __syncthreads();
-                apply_pivot(r, q, false, 0);
-                __syncthreads();
-                npiv++;
-            }
-        }
-
-        // ---- 2. nonbasic sides, basic values ------------------------------------------------
-        for (int j = tid; j < n; j += NT) {
-            const int v = s.nvar[j];
-            const double lo = vlo(v), up = vup(v);
-            const double dj = s.d[j];
-            int side;
-            if (lo == up) side = 0;
-            else if (dj < -kDTol) side = isinf(up) ? 2 : 1;
-            else if (dj > kDTol) side = 0;
-            else side = (s.atup[v] && !isinf(up)) ? 1 : 0;
-            s.side[j] = side;
-            s.va[j] = side == 0 ? lo : side == 1 ? up : 0.0;
-            s.vb[j] = side == 2 ? 1.0 : 0.0;
-        }
-        __syncthreads();
-        {
-            double va[C], vb[C];
-#pragma unroll
-            for (int jj = 0; jj < C; jj++) {
-                va[jj] = s.va[bj + TBJ * jj];
-                vb[jj] = s.vb[bj + TBJ * jj];
-            }
-#pragma unroll
-            for (int ii = 0; ii < R; ii++) {
-                double pa[C], pb[C];
-#pragma unroll
-                for (int jj = 0; jj < C; jj++) {
-                    pa[jj] = T[ii][jj] * va[jj];
-                    pb[jj] = T[ii][jj] * vb[jj];
+                r = __builtin_amdgcn_readfirstlane(best.idx);
+                if (r < 0) { __syncthreads(); continue; }  // singular: stays nonbasic
+            } else if (phase == 1) {
+                // ---- 2. nonbasic sides, basic values ----------------------------------------
+#pragma unroll 1
+                for (int j = tid; j < n; j += NT) {
+                    const int v = s.nvar[j];
+                    const double lo = v < n ? s.lo[v] : 0.0, up = v < n ? s.up[v] : INF;
+                    const double dj = s.d[j];
+                    int side;
+                    if (lo == up) side = 0;
+                    else if (dj < -kDTol) side = isinf(up) ? 2 : 1;
+                    else if (dj > kDTol) side = 0;
+                    else side = (s.atup[v] && !isinf(up)) ? 1 : 0;
+                    s.side[j] = side;
+                    s.va[j] = side == 0 ? lo : side == 1 ? up : 0.0;
+                    s.vb[j] = side == 2 ? 1.0 : 0.0;
                 }
+                __syncthreads();
+                {
+                    double va[C], vb[C];
 #pragma unroll
-                for (int h = C / 2; h >= 1; h >>= 1) {
+                    for (int jj = 0; jj < C; jj++) {
+                        va[jj] = s.va[bj + TBJ * jj];
+                        vb[jj] = s.vb[bj + TBJ * jj];
+                    }
 #pragma unroll
-                    for (int jj = 0; jj < h; jj++) {
-                        pa[jj] = pa[jj] + pa[jj + h];
-                        pb[jj] = pb[jj] + pb[jj + h];
+                    for (int ii = 0; ii < R; ii++) {
+                        double pa[C], pb[C];
+#pragma unroll
+                        for (int jj = 0; jj < C; jj++) {
+                            pa[jj] = T[ii][jj] * va[jj];
+                            pb[jj] = T[ii][jj] * vb[jj];
+                        }
+#pragma unroll
+                        for (int h = C / 2; h >= 1; h >>= 1) {
+#pragma unroll
+                            for (int jj = 0; jj < h; jj++) {
+                                pa[jj] = pa[jj] + pa[jj + h];
+                                pb[jj] = pb[jj] + pb[jj + h];
+                            }
+                        }
+                        double sa = pa[0], sb = pb[0];
+#pragma unroll
+                        for (int h = TBJ / 2; h >= 1; h >>= 1) {
+                            sa = sa + __shfl_down(sa, h, TBJ);
+                            sb = sb + __shfl_down(sb, h, TBJ);
+                        }
+                        const int i = bi + TBI * ii;
+                        if (bj == 0 && i < m) {
+                            s.ba[i] = s.beta0[i] - sa;
+                            s.bb[i] = 0.0 - sb;
+                        }
+                        // keep the rows' temporaries from being interleaved (register pressure)
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                double sa = pa[0], sb = pb[0];
-#pragma unroll
-                for (int h = TBJ / 2; h >= 1; h >>= 1) {
-                    sa = sa + __shfl_down(sa, h, TBJ);
-                    sb = sb + __shfl_down(sb, h, TBJ);
+                __syncthreads();
+                phase = 2;
+                continue;
+            } else {
+                // ---- 3. dual simplex iteration ----------------------------------------------
+                // (a) leaving row: every wave reduces redundantly (no barrier to publish it)
+                Best best{-1, 0.0, 0, -1};
+#pragma unroll 1
+                for (int i = lane; i < m; i += 64) {
+                    const int v = s.bvar[i];
+                    const double lo = v < n ? s.lo[v] : 0.0, up = v < n ? s.up[v] : INF;
+                    const double a = s.ba[i], bM = s.bb[i];
+                    int level = 0, sg = 0;
+                    double viol = 0.0;
+                    if (bM < -kBTol) { level = 2; viol = -bM; sg = 1; }
+                    else if (bM > kBTol) {
+                        if (!isinf(up)) { level = 2; viol = bM; sg = -1; }
+                        else if (bM > 1.0 + kBTol) { level = 2; viol = bM - 1.0; sg = -1; }
+                        else if (bM >= 1.0 - kBTol && a > kPTol) { level = 1; viol = a; sg = -1; }
+                    } else {
+                        if (a < lo - kPTol) { level = 1; viol = lo - a; sg = 1; }
+                        else if (!isinf(up) && a > up + kPTol) { level = 1; viol = a - up; sg = -1; }
+                    }
+                    const Best cand{level, viol, v, sg > 0 ? i : (i | (1 << 30))};
+                    take(best, cand, level > 0);
                 }
-                const int i = bi + TBI * ii;
-                if (bj == 0 && i < m) {
-                    s.ba[i] = s.beta0[i] - sa;
-                    s.bb[i] = 0.0 - sb;
+                best = wave_best(best);
+                if (__builtin_amdgcn_readfirstlane(best.hi) < 0) {
+                    int bad = 0;
+                    for (int i = lane; i < m; i += 64) bad |= s.bb[i] > kBTol;
+                    for (int j = lane; j < n; j += 64) bad |= s.side[j] == 2;
+                    status = __any(bad) ? 2 : 0;
+                    break;
                 }
-                // keep the rows' temporaries from being interleaved (register pressure)
-                __builtin_amdgcn_sched_barrier(0);
+                if ((g.max_iter > 0 && iters >= g.max_iter) || iters >= cap) { status = 3; break; }
+                const int ridx = __builtin_amdgcn_readfirstlane(best.idx);
+                r = ridx & ~(1 << 30);
+                sigma = (ridx & (1 << 30)) ? -1 : 1;
             }
-        }
-        __syncthreads();
 
-        // ---- 3. dual simplex ---------------------------------------------------------------
-        int iters = 0, status = -1;
-        const int cap = 100 * (m + n) + 1000;
-        for (;;) {
-            // (a) leaving row: every wave reduces redundantly
-            Best best{-1, 0.0, 0, -1};
-            for (int i = lane; i < m; i += 64) {
-                const int v = s.bvar[i];
-                const double lo = vlo(v), up = vup(v);
-                const double a = s.ba[i], bM = s.bb[i];
-                int level = 0, sg = 0;
-                double viol = 0.0;
-                if (bM < -kBTol) { level = 2; viol = -bM; sg = 1; }
-                else if (bM > kBTol) {
-                    if (!isinf(up)) { level = 2; viol = bM; sg = -1; }
-                    else if (bM > 1.0 + kBTol) { level = 2; viol = bM - 1.0; sg = -1; }
-                    else if (bM >= 1.0 - kBTol && a > kPTol) { level = 1; viol = a; sg = -1; }
-                } else {
-                    if (a < lo - kPTol) { level = 1; viol = lo - a; sg = 1; }
-                    else if (!isinf(up) && a > up + kPTol) { level = 1; viol = a - up; sg = -1; }
-                }
-                const Best cand{level, viol, v, sg > 0 ? i : (i | (1 << 30))};
-                take(best, cand, level > 0);
-            }
-            best = wave_best(best);
-            if (__builtin_amdgcn_readfirstlane(best.hi) < 0) {
-                int bad = 0;
-                for (int i = lane; i < m; i += 64) bad |= s.bb[i] > kBTol;
-                for (int j = lane; j < n; j += 64) bad |= s.side[j] == 2;
-                status = __any(bad) ? 2 : 0;
-                break;
-            }
-            if ((g.max_iter > 0 && iters >= g.max_iter) || iters >= cap) { status = 3; break; }
-            const int ridx = __builtin_amdgcn_readfirstlane(best.idx);
-            const int r = ridx & ~(1 << 30);
-            const int sigma = (ridx & (1 << 30)) ? -1 : 1;
-
-            // (b) pivot row to LDS
-            extract_row(r);
-            __syncthreads();
-
-            // (c) Harris ratio test
-            for (int j = tid; j < n; j += NT) {
-                const int v = s.nvar[j];
-                const double a = sigma * s.row[j];
-                const int sd = s.side[j];
-                bool elig = vlo(v) != vup(v) && (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
-                const double dj = sd == 0 ? fmax(s.d[j], 0.0) : fmax(-s.d[j], 0.0);
-                const double aa = fabs(a);
-                s.key[j] = elig ? (dj + kDTol) / aa : INF;
-                s.aabs[j] = elig ? aa : -1.0;
-                s.dje[j] = dj;
-            }
-            __syncthreads();
-            Best mn{-1, 0.0, 0, -1};
-            for (int j = lane; j < n; j += 64) {
-                const Best cand{0, -s.key[j], s.nvar[j], j};
-                take(mn, cand, s.aabs[j] >= 0.0);
-            }
-            mn = wave_best(mn);
-            if (__builtin_amdgcn_readfirstlane(mn.hi) < 0) { status = 1; break; }
-            const double thmax = -mn.key;
-            const int jmin = __builtin_amdgcn_readfirstlane(mn.idx);
-            Best bq{-1, 0.0, 0, -1};
-            for (int j = lane; j < n; j += 64) {
-                const double aa = s.aabs[j];
-                const bool ok = aa >= 0.0 && (j == jmin || !(s.dje[j] > thmax * aa));
-                const Best cand{0, aa, s.nvar[j], j};
-                take(bq, cand, ok);
-            }
-            bq = wave_best(bq);
-            const int q = __builtin_amdgcn_readfirstlane(bq.idx);
-
-            // (d) pivot column to LDS, leaving-variable target
-            extract_col(q);
-            const int lv = s.bvar[r];
-            double la, lb;
-            int newside;
+            // ---- pivot row r -> s.row (both pivoting phases) --------------------------------
             {
-                const double lo = vlo(lv), up = vup(lv);
+                const int rb = r % TBI, rl = r / TBI;
+                if (bi == rb) {
+#pragma unroll
+                    for (int ii = 0; ii < R; ii++)
+                        if (ii == rl) {
+#pragma unroll
+                            for (int jj = 0; jj < C; jj++) s.row[bj + TBJ * jj] = T[ii][jj];
+                        }
+                }
+            }
+
+            if (phase == 2) {
+                __syncthreads();
+                // (c) Harris ratio test on row r
+#pragma unroll 1
+                for (int j = tid; j < n; j += NT) {
+                    const int v = s.nvar[j];
+                    const double lo = v < n ? s.lo[v] : 0.0, up = v < n ? s.up[v] : INF;
+                    const double a = sigma * s.row[j];
+                    const int sd = s.side[j];
+                    const bool elig = lo != up && (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
+                    const double dj = sd == 0 ? fmax(s.d[j], 0.0) : fmax(-s.d[j], 0.0);
+                    const double aa = fabs(a);
+                    s.key[j] = elig ? (dj + kDTol) / aa : INF;
+                    s.aabs[j] = elig ? aa : -1.0;
+                    s.dje[j] = dj;
+                }
+                __syncthreads();
+                Best mn{-1, 0.0, 0, -1};
+#pragma unroll 1
+                for (int j = lane; j < n; j += 64) {
+                    const Best cand{0, -s.key[j], s.nvar[j], j};
+                    take(mn, cand, s.aabs[j] >= 0.0);
+                }
+                mn = wave_best(mn);
+                if (__builtin_amdgcn_readfirstlane(mn.hi) < 0) { status = 1; break; }
+                const double thmax = -mn.key;
+                const int jmin = __builtin_amdgcn_readfirstlane(mn.idx);
+                Best bq{-1, 0.0, 0, -1};
+#pragma unroll 1
+                for (int j = lane; j < n; j += 64) {
+                    const double aa = s.aabs[j];
+                    const bool ok = aa >= 0.0 && (j == jmin || !(s.dje[j] > thmax * aa));
+                    const Best cand{0, aa, s.nvar[j], j};
+                    take(bq, cand, ok);
+                }
+                bq = wave_best(bq);
+                q = __builtin_amdgcn_readfirstlane(bq.idx);
+                {   // (d) column q -> s.alpha
+                    const int qb = q % TBJ, ql = q / TBJ;
+                    if (bj == qb) {
+#pragma unroll
+                        for (int jj = 0; jj < C; jj++)
+                            if (jj == ql) {
+#pragma unroll
+                                for (int ii = 0; ii < R; ii++) s.alpha[bi + TBI * ii] = T[ii][jj];
+                            }
+                    }
+                }
+                const int lv = s.bvar[r];
+                const double lo = lv < n ? s.lo[lv] : 0.0, up = lv < n ? s.up[lv] : INF;
                 if (sigma > 0) { la = lo; lb = 0.0; newside = 0; }
                 else if (!isinf(up)) { la = up; lb = 0.0; newside = 1; }
                 else { la = 0.0; lb = 1.0; newside = 2; }
             }
+
+            // scalars every thread needs for the border updates: read BEFORE the barrier,
+            // written (by their owner threads) only after it
+            const double dq = s.d[q], b0r = s.beta0[r];
+            const double bar = s.ba[r], bbr = s.bb[r], vaq = s.va[q], vbq = s.vb[q];
             __syncthreads();
-            // (e) rho, coln, scalars
-            prepare_pivot(r, q, true, la, lb);
+
+            // ---- rank-1 update of the register tableau and the borders ----------------------
+            {
+                const bool vals = phase == 2;
+                const int rb = r % TBI, rl = r / TBI;
+                const int qb = q % TBJ, ql = q / TBJ;
+                const double pinv = 1.0 / s.row[q];
+                double al[R], rh[C];
+#pragma unroll
+                for (int ii = 0; ii < R; ii++) al[ii] = s.alpha[bi + TBI * ii];
+#pragma unroll
+                for (int jj = 0; jj < C; jj++) rh[jj] = s.row[bj + TBJ * jj] * pinv;
+#pragma unroll
+                for (int ii = 0; ii < R; ii++) {
+                    const double a = (bi == rb && ii == rl) ? 0.0 : al[ii];
+#pragma unroll
+                    for (int jj = 0; jj < C; jj++) {
+                        const double h = (bj == qb && jj == ql) ? 0.0 : rh[jj];
+                        T[ii][jj] = fma(-a, h, T[ii][jj]);
+                    }
+                }
+                if (bj == qb) {  // column q <- -alpha * (1/p)
+#pragma unroll
+                    for (int jj = 0; jj < C; jj++)
+                        if (jj == ql) {
+#pragma unroll
+                            for (int ii = 0; ii < R; ii++) T[ii][jj] = -al[ii] * pinv;
+                        }
+                }
+                if (bi == rb) {  // row r <- row * (1/p), and 1/p at the pivot position
+#pragma unroll
+                    for (int ii = 0; ii < R; ii++)
+                        if (ii == rl) {
+#pragma unroll
+                            for (int jj = 0; jj < C; jj++)
+                                T[ii][jj] = (bj == qb && jj == ql) ? pinv : rh[jj];
+                        }
+                }
+                const double rhon = b0r * pinv;
+                const double ta = (bar - la) * pinv, tb = (bbr - lb) * pinv;
+#pragma unroll 1
+                for (int i = tid; i < m; i += NT) {
+                    const double a = s.alpha[i];
+                    if (i == r) {
+                        s.beta0[i] = rhon;
+                        if (vals) { s.ba[i] = vaq + ta; s.bb[i] = vbq + tb; }
+                    } else {
+                        s.beta0[i] = fma(-a, rhon, s.beta0[i]);
+                        if (vals) {
+                            s.ba[i] = fma(-a, ta, s.ba[i]);
+                            s.bb[i] = fma(-a, tb, s.bb[i]);
+                        }
+                    }
+                }
+#pragma unroll 1
+                for (int j = tid; j < n; j += NT) {
+                    if (j == q) {
+                        s.d[j] = -dq * pinv;
+                        if (vals) { s.side[j] = newside; s.va[j] = la; s.vb[j] = lb; }
+                    } else {
+                        s.d[j] = fma(-dq, s.row[j] * pinv, s.d[j]);
+                    }
+                }
+                if (tid == NT - 1) {
+                    const int tmp = s.bvar[r];
+                    s.bvar[r] = s.nvar[q];
+                    s.nvar[q] = tmp;
+                }
+            }
             __syncthreads();
-            // (f) update
-            apply_pivot(r, q, true, newside);
-            __syncthreads();
-            iters++;
             npiv++;
+            if (phase == 2) iters++;
         }
 
         // ---- 4. outputs --------------------------------------------------------------------
