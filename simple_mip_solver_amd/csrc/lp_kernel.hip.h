@@ -51,39 +51,60 @@ struct LpArgs {
     int32_t *dbg_idx;   // [nvar (n) | bvar (m) | side (n)]
 };
 
-struct Best {
-    int hi;      // maximise
-    double key;  // then maximise
-    int lo;      // then minimise
-    int idx;     // payload
-};
-
-__device__ __forceinline__ bool better(const Best &a, const Best &b) {
-    if (a.hi != b.hi) return a.hi > b.hi;
-    if (a.key != b.key) return a.key > b.key;
-    return a.lo < b.lo;
+// ---- wavefront-wide reductions on DPP (row_shr prefix-doubling inside each row of 16 lanes,
+// then row_bcast:15 / row_bcast:31 across rows; the total lands in lane 63 and is read back with
+// v_readlane, i.e. the result is wave-uniform).  A few dozen low-latency VALU instructions
+// instead of 6 rounds of ds_bpermute.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
 }
-
-// branch-free "cur = valid && better(cand, cur) ? cand : cur"
-__device__ __forceinline__ void take(Best &cur, const Best &cand, bool valid) {
-    const bool b = valid && better(cand, cur);
-    cur.hi = b ? cand.hi : cur.hi;
-    cur.key = b ? cand.key : cur.key;
-    cur.lo = b ? cand.lo : cur.lo;
-    cur.idx = b ? cand.idx : cur.idx;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = dpp_i32<CTRL, ROW_MASK>(__double2loint(v));
+    const int hi = dpp_i32<CTRL, ROW_MASK>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
-
-__device__ __forceinline__ Best wave_best(Best v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        Best o;
-        o.hi = __shfl_xor(v.hi, off);
-        o.key = __shfl_xor(v.key, off);
-        o.lo = __shfl_xor(v.lo, off);
-        o.idx = __shfl_xor(v.idx, off);
-        take(v, o, true);
-    }
-    return v;
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = fmax(v, dpp_f64<0x111, 0xf>(v));  // row_shr:1
+    v = fmax(v, dpp_f64<0x112, 0xf>(v));  // row_shr:2
+    v = fmax(v, dpp_f64<0x114, 0xf>(v));  // row_shr:4
+    v = fmax(v, dpp_f64<0x118, 0xf>(v));  // row_shr:8
+    v = fmax(v, dpp_f64<0x142, 0xa>(v));  // row_bcast:15 -> rows 1,3
+    v = fmax(v, dpp_f64<0x143, 0xc>(v));  // row_bcast:31 -> rows 2,3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, dpp_i32<0x111, 0xf>(v));
+    v = min(v, dpp_i32<0x112, 0xf>(v));
+    v = min(v, dpp_i32<0x114, 0xf>(v));
+    v = min(v, dpp_i32<0x118, 0xf>(v));
+    v = min(v, dpp_i32<0x142, 0xa>(v));
+    v = min(v, dpp_i32<0x143, 0xc>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+    v = max(v, dpp_i32<0x111, 0xf>(v));
+    v = max(v, dpp_i32<0x112, 0xf>(v));
+    v = max(v, dpp_i32<0x114, 0xf>(v));
+    v = max(v, dpp_i32<0x118, 0xf>(v));
+    v = max(v, dpp_i32<0x142, 0xa>(v));
+    v = max(v, dpp_i32<0x143, 0xc>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+constexpr int kNoCand = 0x7fffffff;
+// lane-local "keep the better candidate": larger key wins, ties go to the smaller payload
+__device__ __forceinline__ void keep(double &bk, int &bp, double k, int p, bool valid) {
+    const bool b = valid && (k > bk || (k == bk && p < bp));
+    bk = b ? k : bk;
+    bp = b ? p : bp;
+}
+// wave-wide argmax of (key, then smallest payload); kNoCand if no lane holds a candidate
+__device__ __forceinline__ int wave_argmax(double key, int payload, double &kmax) {
+    kmax = wave_max_f64(key);
+    return wave_min_i32((payload != kNoCand && key == kmax) ? payload : kNoCand);
 }
 
 template <int MP, int NP>
@@ -117,6 +138,8 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
     constexpr int NP = TBJ * C;
     static_assert((NP & (NP - 1)) == 0, "padded column count must be a power of two");
     static_assert(NT % 64 == 0, "whole waves only");
+    constexpr int PI = (MP + 63) / 64;  // rows per lane in a wave-wide scan
+    constexpr int PJ = (NP + 63) / 64;  // columns per lane in a wave-wide scan
     __shared__ Smem<MP, NP> s;
 
     const int tid = threadIdx.x;
@@ -212,19 +235,23 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                     }
                 }
                 __syncthreads();
-                Best best{-1, 0.0, 0, -1}, fb{-1, 0.0, 0, -1};
-#pragma unroll 1
-                for (int i = lane; i < m; i += 64) {
-                    const int bv = s.bvar[i];
-                    const double a = fabs(s.alpha[i]);
-                    const bool ok = bv >= n && a > kPivTol;
-                    const Best cand{0, a, i, i};
-                    take(fb, cand, ok);
-                    take(best, cand, ok && !s.wantb[bv >= n ? bv : n]);
+                double k1 = -INF, k2 = -INF;   // preferred rows / any slack row
+                int p1 = kNoCand, p2 = kNoCand;
+#pragma unroll
+                for (int kk = 0; kk < PI; kk++) {
+                    const int i = lane + 64 * kk;
+                    if (i < m) {
+                        const int bv = s.bvar[i];
+                        const double a = fabs(s.alpha[i]);
+                        const bool ok = bv >= n && a > kPivTol;
+                        keep(k2, p2, a, i, ok);
+                        keep(k1, p1, a, i, ok && !s.wantb[bv >= n ? bv : n]);
+                    }
                 }
-                best = wave_best(best);
-                if (__builtin_amdgcn_readfirstlane(best.hi) < 0) best = wave_best(fb);
-                r = __builtin_amdgcn_readfirstlane(best.idx);
+                double km;
+                r = wave_argmax(k1, p1, km);
+                if (r == kNoCand) r = wave_argmax(k2, p2, km);
+                if (r == kNoCand) r = -1;
                 if (r < 0) { __syncthreads(); continue; }  // singular: stays nonbasic
             } else if (phase == 1) {
                 // ---- 2. nonbasic sides, basic values ----------------------------------------
@@ -287,28 +314,36 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
             } else {
                 // ---- 3. dual simplex iteration ----------------------------------------------
                 // (a) leaving row: every wave reduces redundantly (no barrier to publish it)
-                Best best{-1, 0.0, 0, -1};
-#pragma unroll 1
-                for (int i = lane; i < m; i += 64) {
-                    const int v = s.bvar[i];
-                    const double lo = v < n ? s.lo[v] : 0.0, up = v < n ? s.up[v] : INF;
-                    const double a = s.ba[i], bM = s.bb[i];
-                    int level = 0, sg = 0;
-                    double viol = 0.0;
-                    if (bM < -kBTol) { level = 2; viol = -bM; sg = 1; }
-                    else if (bM > kBTol) {
-                        if (!isinf(up)) { level = 2; viol = bM; sg = -1; }
-                        else if (bM > 1.0 + kBTol) { level = 2; viol = bM - 1.0; sg = -1; }
-                        else if (bM >= 1.0 - kBTol && a > kPTol) { level = 1; viol = a; sg = -1; }
-                    } else {
-                        if (a < lo - kPTol) { level = 1; viol = lo - a; sg = 1; }
-                        else if (!isinf(up) && a > up + kPTol) { level = 1; viol = a - up; sg = -1; }
+                int blevel = 0, bp = kNoCand;
+                double bk = -INF;
+#pragma unroll
+                for (int kk = 0; kk < PI; kk++) {
+                    const int i = lane + 64 * kk;
+                    if (i < m) {
+                        const int v = s.bvar[i];
+                        const double lo = v < n ? s.lo[v] : 0.0, up = v < n ? s.up[v] : INF;
+                        const double a = s.ba[i], bM = s.bb[i];
+                        int level = 0, sg = 0;
+                        double viol = 0.0;
+                        if (bM < -kBTol) { level = 2; viol = -bM; sg = 1; }
+                        else if (bM > kBTol) {
+                            if (!isinf(up)) { level = 2; viol = bM; sg = -1; }
+                            else if (bM > 1.0 + kBTol) { level = 2; viol = bM - 1.0; sg = -1; }
+                            else if (bM >= 1.0 - kBTol && a > kPTol) { level = 1; viol = a; sg = -1; }
+                        } else {
+                            if (a < lo - kPTol) { level = 1; viol = lo - a; sg = 1; }
+                            else if (!isinf(up) && a > up + kPTol) { level = 1; viol = a - up; sg = -1; }
+                        }
+                        // payload: variable index (tie-break), direction flag, row
+                        const int pay = (v << 16) | (sg < 0 ? 0x8000 : 0) | i;
+                        const bool up_lvl = level > blevel;
+                        const bool same = level == blevel && level > 0 &&
+                                          (viol > bk || (viol == bk && pay < bp));
+                        if (up_lvl || same) { blevel = level; bk = viol; bp = pay; }
                     }
-                    const Best cand{level, viol, v, sg > 0 ? i : (i | (1 << 30))};
-                    take(best, cand, level > 0);
                 }
-                best = wave_best(best);
-                if (__builtin_amdgcn_readfirstlane(best.hi) < 0) {
+                const int lvl = wave_max_i32(blevel);
+                if (lvl == 0) {
                     int bad = 0;
                     for (int i = lane; i < m; i += 64) bad |= s.bb[i] > kBTol;
                     for (int j = lane; j < n; j += 64) bad |= s.side[j] == 2;
@@ -316,9 +351,10 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                     break;
                 }
                 if ((g.max_iter > 0 && iters >= g.max_iter) || iters >= cap) { status = 3; break; }
-                const int ridx = __builtin_amdgcn_readfirstlane(best.idx);
-                r = ridx & ~(1 << 30);
-                sigma = (ridx & (1 << 30)) ? -1 : 1;
+                double km;
+                const int win = wave_argmax(blevel == lvl ? bk : -INF, blevel == lvl ? bp : kNoCand, km);
+                r = win & 0x7fff;
+                sigma = (win & 0x8000) ? -1 : 1;
             }
 
             // ---- pivot row r -> s.row (both pivoting phases) --------------------------------
@@ -351,26 +387,31 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                     s.dje[j] = dj;
                 }
                 __syncthreads();
-                Best mn{-1, 0.0, 0, -1};
-#pragma unroll 1
-                for (int j = lane; j < n; j += 64) {
-                    const Best cand{0, -s.key[j], s.nvar[j], j};
-                    take(mn, cand, s.aabs[j] >= 0.0);
+                double k1 = -INF;
+                int p1 = kNoCand;
+#pragma unroll
+                for (int kk = 0; kk < PJ; kk++) {
+                    const int j = lane + 64 * kk;
+                    if (j < n) keep(k1, p1, -s.key[j], (s.nvar[j] << 16) | j, s.aabs[j] >= 0.0);
                 }
-                mn = wave_best(mn);
-                if (__builtin_amdgcn_readfirstlane(mn.hi) < 0) { status = 1; break; }
-                const double thmax = -mn.key;
-                const int jmin = __builtin_amdgcn_readfirstlane(mn.idx);
-                Best bq{-1, 0.0, 0, -1};
-#pragma unroll 1
-                for (int j = lane; j < n; j += 64) {
-                    const double aa = s.aabs[j];
-                    const bool ok = aa >= 0.0 && (j == jmin || !(s.dje[j] > thmax * aa));
-                    const Best cand{0, aa, s.nvar[j], j};
-                    take(bq, cand, ok);
+                double nthmax;
+                const int w1 = wave_argmax(k1, p1, nthmax);
+                if (w1 == kNoCand) { status = 1; break; }
+                const double thmax = -nthmax;
+                const int jmin = w1 & 0xffff;
+                double k2 = -INF;
+                int p2 = kNoCand;
+#pragma unroll
+                for (int kk = 0; kk < PJ; kk++) {
+                    const int j = lane + 64 * kk;
+                    if (j < n) {
+                        const double aa = s.aabs[j];
+                        const bool ok = aa >= 0.0 && (j == jmin || !(s.dje[j] > thmax * aa));
+                        keep(k2, p2, aa, (s.nvar[j] << 16) | j, ok);
+                    }
                 }
-                bq = wave_best(bq);
-                q = __builtin_amdgcn_readfirstlane(bq.idx);
+                double amax;
+                q = wave_argmax(k2, p2, amax) & 0xffff;
                 {   // (d) column q -> s.alpha
                     const int qb = q % TBJ, ql = q / TBJ;
                     if (bj == qb) {
