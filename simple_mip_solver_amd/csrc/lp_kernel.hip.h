@@ -127,6 +127,8 @@ struct Smem {
     int side[NP];      // 0 lower, 1 upper, 2 fake upper
     int wlist[NP];     // structurals the warm start wants basic, ascending
     int nw;
+    int ci[4];         // control words published by the control waves
+    double cd[2];
     int8_t wantb[NP + MP];
     int8_t atup[NP + MP];
 };
@@ -213,10 +215,16 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
         int phase = vin ? 0 : 1;  // 0 refactor, 1 value initialisation, 2 dual simplex
         int w = 0;
         const int cap = 100 * (m + n) + 1000;
+        // Role split: the selections (pivot row / ratio test) are done by the "control" waves only
+        // -- the first wave on each SIMD -- and published through LDS; their sibling waves on the
+        // same SIMDs skip that work instead of repeating it (it would just double the SIMD's
+        // instruction stream).  All waves take part in the tableau update.
+        constexpr int CT = NT < 256 ? NT : 256;
+        const bool ctl = tid < CT;
 
         for (;;) {
             int r = 0, q = 0, sigma = 1, newside = 0;
-            double la = 0.0, lb = 0.0;
+            double la = 0.0, lb = 0.0, pinv = 0.0;
 
             if (phase == 0) {
                 // ---- 1. refactor: pivot the next wanted structural into the basis -----------
@@ -235,24 +243,43 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                     }
                 }
                 __syncthreads();
-                double k1 = -INF, k2 = -INF;   // preferred rows / any slack row
-                int p1 = kNoCand, p2 = kNoCand;
+                if (ctl) {
+                    double k1 = -INF, k2 = -INF;   // preferred rows / any slack row
+                    int p1 = kNoCand, p2 = kNoCand;
 #pragma unroll
-                for (int kk = 0; kk < PI; kk++) {
-                    const int i = lane + 64 * kk;
-                    if (i < m) {
-                        const int bv = s.bvar[i];
-                        const double a = fabs(s.alpha[i]);
-                        const bool ok = bv >= n && a > kPivTol;
-                        keep(k2, p2, a, i, ok);
-                        keep(k1, p1, a, i, ok && !s.wantb[bv >= n ? bv : n]);
+                    for (int kk = 0; kk < PI; kk++) {
+                        const int i = lane + 64 * kk;
+                        if (i < m) {
+                            const int bv = s.bvar[i];
+                            const double a = fabs(s.alpha[i]);
+                            const bool ok = bv >= n && a > kPivTol;
+                            keep(k2, p2, a, i, ok);
+                            keep(k1, p1, a, i, ok && !s.wantb[bv >= n ? bv : n]);
+                        }
+                    }
+                    double km;
+                    int rr = wave_argmax(k1, p1, km);
+                    if (rr == kNoCand) rr = wave_argmax(k2, p2, km);
+                    if (tid == 0) {
+                        s.ci[0] = rr == kNoCand ? -1 : rr;
+                        if (rr != kNoCand) s.cd[0] = 1.0 / s.alpha[rr];  // 1/p, p = T[r][q]
                     }
                 }
-                double km;
-                r = wave_argmax(k1, p1, km);
-                if (r == kNoCand) r = wave_argmax(k2, p2, km);
-                if (r == kNoCand) r = -1;
-                if (r < 0) { __syncthreads(); continue; }  // singular: stays nonbasic
+                __syncthreads();
+                r = __builtin_amdgcn_readfirstlane(s.ci[0]);
+                if (r < 0) continue;  // singular: stays nonbasic
+                pinv = s.cd[0];
+                {   // row r -> s.row
+                    const int rb = r % TBI, rl = r / TBI;
+                    if (bi == rb) {
+#pragma unroll
+                        for (int ii = 0; ii < R; ii++)
+                            if (ii == rl) {
+#pragma unroll
+                                for (int jj = 0; jj < C; jj++) s.row[bj + TBJ * jj] = T[ii][jj];
+                            }
+                    }
+                }
             } else if (phase == 1) {
                 // ---- 2. nonbasic sides, basic values ----------------------------------------
 #pragma unroll 1
@@ -313,105 +340,125 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                 continue;
             } else {
                 // ---- 3. dual simplex iteration ----------------------------------------------
-                // (a) leaving row: every wave reduces redundantly (no barrier to publish it)
-                int blevel = 0, bp = kNoCand;
-                double bk = -INF;
+                // (a) leaving row, by the control waves
+                if (ctl) {
+                    int blevel = 0, bp = kNoCand;
+                    double bk = -INF;
 #pragma unroll
-                for (int kk = 0; kk < PI; kk++) {
-                    const int i = lane + 64 * kk;
-                    if (i < m) {
-                        const int v = s.bvar[i];
-                        const double lo = v < n ? s.lo[v] : 0.0, up = v < n ? s.up[v] : INF;
-                        const double a = s.ba[i], bM = s.bb[i];
-                        int level = 0, sg = 0;
-                        double viol = 0.0;
-                        if (bM < -kBTol) { level = 2; viol = -bM; sg = 1; }
-                        else if (bM > kBTol) {
-                            if (!isinf(up)) { level = 2; viol = bM; sg = -1; }
-                            else if (bM > 1.0 + kBTol) { level = 2; viol = bM - 1.0; sg = -1; }
-                            else if (bM >= 1.0 - kBTol && a > kPTol) { level = 1; viol = a; sg = -1; }
-                        } else {
-                            if (a < lo - kPTol) { level = 1; viol = lo - a; sg = 1; }
-                            else if (!isinf(up) && a > up + kPTol) { level = 1; viol = a - up; sg = -1; }
+                    for (int kk = 0; kk < PI; kk++) {
+                        const int i = lane + 64 * kk;
+                        if (i < m) {
+                            const int v = s.bvar[i];
+                            const double lo = v < n ? s.lo[v] : 0.0, up = v < n ? s.up[v] : INF;
+                            const double a = s.ba[i], bM = s.bb[i];
+                            int level = 0, sg = 0;
+                            double viol = 0.0;
+                            if (bM < -kBTol) { level = 2; viol = -bM; sg = 1; }
+                            else if (bM > kBTol) {
+                                if (!isinf(up)) { level = 2; viol = bM; sg = -1; }
+                                else if (bM > 1.0 + kBTol) { level = 2; viol = bM - 1.0; sg = -1; }
+                                else if (bM >= 1.0 - kBTol && a > kPTol) { level = 1; viol = a; sg = -1; }
+                            } else {
+                                if (a < lo - kPTol) { level = 1; viol = lo - a; sg = 1; }
+                                else if (!isinf(up) && a > up + kPTol) { level = 1; viol = a - up; sg = -1; }
+                            }
+                            // payload: variable index (tie-break), direction flag, row
+                            const int pay = (v << 16) | (sg < 0 ? 0x8000 : 0) | i;
+                            const bool up_lvl = level > blevel;
+                            const bool same = level == blevel && level > 0 &&
+                                              (viol > bk || (viol == bk && pay < bp));
+                            if (up_lvl || same) { blevel = level; bk = viol; bp = pay; }
                         }
-                        // payload: variable index (tie-break), direction flag, row
-                        const int pay = (v << 16) | (sg < 0 ? 0x8000 : 0) | i;
-                        const bool up_lvl = level > blevel;
-                        const bool same = level == blevel && level > 0 &&
-                                          (viol > bk || (viol == bk && pay < bp));
-                        if (up_lvl || same) { blevel = level; bk = viol; bp = pay; }
+                    }
+                    const int lvl = wave_max_i32(blevel);
+                    int cmd = 0, win = 0;
+                    if (lvl == 0) {
+                        int bad = 0;
+                        for (int i = lane; i < m; i += 64) bad |= s.bb[i] > kBTol;
+                        for (int j = lane; j < n; j += 64) bad |= s.side[j] == 2;
+                        cmd = __any(bad) ? 3 : 1;  // exit: unbounded / optimal
+                    } else if ((g.max_iter > 0 && iters >= g.max_iter) || iters >= cap) {
+                        cmd = 4;                   // exit: iteration limit
+                    } else {
+                        double km;
+                        win = wave_argmax(blevel == lvl ? bk : -INF, blevel == lvl ? bp : kNoCand, km);
+                    }
+                    if (tid == 0) { s.ci[0] = cmd; s.ci[1] = win; }
+                }
+                __syncthreads();
+                {
+                    const int cmd = __builtin_amdgcn_readfirstlane(s.ci[0]);
+                    if (cmd) { status = cmd == 1 ? 0 : cmd == 3 ? 2 : 3; break; }
+                    const int win = __builtin_amdgcn_readfirstlane(s.ci[1]);
+                    r = win & 0x7fff;
+                    sigma = (win & 0x8000) ? -1 : 1;
+                }
+                {   // (b) row r -> s.row
+                    const int rb = r % TBI, rl = r / TBI;
+                    if (bi == rb) {
+#pragma unroll
+                        for (int ii = 0; ii < R; ii++)
+                            if (ii == rl) {
+#pragma unroll
+                                for (int jj = 0; jj < C; jj++) s.row[bj + TBJ * jj] = T[ii][jj];
+                            }
                     }
                 }
-                const int lvl = wave_max_i32(blevel);
-                if (lvl == 0) {
-                    int bad = 0;
-                    for (int i = lane; i < m; i += 64) bad |= s.bb[i] > kBTol;
-                    for (int j = lane; j < n; j += 64) bad |= s.side[j] == 2;
-                    status = __any(bad) ? 2 : 0;
-                    break;
-                }
-                if ((g.max_iter > 0 && iters >= g.max_iter) || iters >= cap) { status = 3; break; }
-                double km;
-                const int win = wave_argmax(blevel == lvl ? bk : -INF, blevel == lvl ? bp : kNoCand, km);
-                r = win & 0x7fff;
-                sigma = (win & 0x8000) ? -1 : 1;
-            }
-
-            // ---- pivot row r -> s.row (both pivoting phases) --------------------------------
-            {
-                const int rb = r % TBI, rl = r / TBI;
-                if (bi == rb) {
-#pragma unroll
-                    for (int ii = 0; ii < R; ii++)
-                        if (ii == rl) {
-#pragma unroll
-                            for (int jj = 0; jj < C; jj++) s.row[bj + TBJ * jj] = T[ii][jj];
-                        }
-                }
-            }
-
-            if (phase == 2) {
                 __syncthreads();
-                // (c) Harris ratio test on row r
+                // (c) Harris ratio test on row r, by the control waves
+                if (ctl) {
 #pragma unroll 1
-                for (int j = tid; j < n; j += NT) {
-                    const int v = s.nvar[j];
-                    const double lo = v < n ? s.lo[v] : 0.0, up = v < n ? s.up[v] : INF;
-                    const double a = sigma * s.row[j];
-                    const int sd = s.side[j];
-                    const bool elig = lo != up && (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
-                    const double dj = sd == 0 ? fmax(s.d[j], 0.0) : fmax(-s.d[j], 0.0);
-                    const double aa = fabs(a);
-                    s.key[j] = elig ? (dj + kDTol) / aa : INF;
-                    s.aabs[j] = elig ? aa : -1.0;
-                    s.dje[j] = dj;
-                }
-                __syncthreads();
-                double k1 = -INF;
-                int p1 = kNoCand;
-#pragma unroll
-                for (int kk = 0; kk < PJ; kk++) {
-                    const int j = lane + 64 * kk;
-                    if (j < n) keep(k1, p1, -s.key[j], (s.nvar[j] << 16) | j, s.aabs[j] >= 0.0);
-                }
-                double nthmax;
-                const int w1 = wave_argmax(k1, p1, nthmax);
-                if (w1 == kNoCand) { status = 1; break; }
-                const double thmax = -nthmax;
-                const int jmin = w1 & 0xffff;
-                double k2 = -INF;
-                int p2 = kNoCand;
-#pragma unroll
-                for (int kk = 0; kk < PJ; kk++) {
-                    const int j = lane + 64 * kk;
-                    if (j < n) {
-                        const double aa = s.aabs[j];
-                        const bool ok = aa >= 0.0 && (j == jmin || !(s.dje[j] > thmax * aa));
-                        keep(k2, p2, aa, (s.nvar[j] << 16) | j, ok);
+                    for (int j = tid; j < n; j += CT) {
+                        const int v = s.nvar[j];
+                        const double lo = v < n ? s.lo[v] : 0.0, up = v < n ? s.up[v] : INF;
+                        const double a = sigma * s.row[j];
+                        const int sd = s.side[j];
+                        const bool elig = lo != up && (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
+                        const double dj = sd == 0 ? fmax(s.d[j], 0.0) : fmax(-s.d[j], 0.0);
+                        const double aa = fabs(a);
+                        s.key[j] = elig ? (dj + kDTol) / aa : INF;
+                        s.aabs[j] = elig ? aa : -1.0;
+                        s.dje[j] = dj;
                     }
                 }
-                double amax;
-                q = wave_argmax(k2, p2, amax) & 0xffff;
+                if (CT > 64) __syncthreads();  // a single control wave needs no barrier here
+                if (ctl) {
+                    double k1 = -INF;
+                    int p1 = kNoCand;
+#pragma unroll
+                    for (int kk = 0; kk < PJ; kk++) {
+                        const int j = lane + 64 * kk;
+                        if (j < n) keep(k1, p1, -s.key[j], (s.nvar[j] << 16) | j, s.aabs[j] >= 0.0);
+                    }
+                    double nthmax;
+                    const int w1 = wave_argmax(k1, p1, nthmax);
+                    int qq = -1;
+                    if (w1 != kNoCand) {
+                        const double thmax = -nthmax;
+                        const int jmin = w1 & 0xffff;
+                        double k2 = -INF;
+                        int p2 = kNoCand;
+#pragma unroll
+                        for (int kk = 0; kk < PJ; kk++) {
+                            const int j = lane + 64 * kk;
+                            if (j < n) {
+                                const double aa = s.aabs[j];
+                                const bool ok = aa >= 0.0 && (j == jmin || !(s.dje[j] > thmax * aa));
+                                keep(k2, p2, aa, (s.nvar[j] << 16) | j, ok);
+                            }
+                        }
+                        double amax;
+                        qq = wave_argmax(k2, p2, amax) & 0xffff;
+                    }
+                    if (tid == 0) {
+                        s.ci[0] = qq;
+                        if (qq >= 0) s.cd[0] = 1.0 / s.row[qq];
+                    }
+                }
+                __syncthreads();
+                q = __builtin_amdgcn_readfirstlane(s.ci[0]);
+                if (q < 0) { status = 1; break; }  // no entering column: primal infeasible
+                pinv = s.cd[0];
                 {   // (d) column q -> s.alpha
                     const int qb = q % TBJ, ql = q / TBJ;
                     if (bj == qb) {
@@ -441,20 +488,16 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                 const bool vals = phase == 2;
                 const int rb = r % TBI, rl = r / TBI;
                 const int qb = q % TBJ, ql = q / TBJ;
-                const double pinv = 1.0 / s.row[q];
                 double al[R], rh[C];
 #pragma unroll
                 for (int ii = 0; ii < R; ii++) al[ii] = s.alpha[bi + TBI * ii];
 #pragma unroll
                 for (int jj = 0; jj < C; jj++) rh[jj] = s.row[bj + TBJ * jj] * pinv;
+                // row r and column q come out of this as junk and are overwritten just below
 #pragma unroll
                 for (int ii = 0; ii < R; ii++) {
-                    const double a = (bi == rb && ii == rl) ? 0.0 : al[ii];
 #pragma unroll
-                    for (int jj = 0; jj < C; jj++) {
-                        const double h = (bj == qb && jj == ql) ? 0.0 : rh[jj];
-                        T[ii][jj] = fma(-a, h, T[ii][jj]);
-                    }
+                    for (int jj = 0; jj < C; jj++) T[ii][jj] = fma(-al[ii], rh[jj], T[ii][jj]);
                 }
                 if (bj == qb) {  // column q <- -alpha * (1/p)
 #pragma unroll
