@@ -116,6 +116,56 @@ int mipx_timer_stop(mipx_ctx *ctx, float *ms);
 int mipx_debug_enable(mipx_problem *p);
 int mipx_debug_read(mipx_problem *p, double *T, double *vec, int32_t *idx);
 
+/* ------------------------------------------------------------------------------------------
+ * Native frontier engine: BranchAndBound.solve() (algorithms/branch_and_bound.py:215-266) for the
+ * stock node classes, a batch of open nodes per step, node records resident in HBM.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mipx_tree mipx_tree;
+
+typedef struct mipx_tree_stats {
+    int64_t evaluated_nodes;  /* BranchAndBound.evaluated_nodes */
+    int64_t lp_solved;        /* node LP relaxations solved to termination (_bound_lp calls) */
+    int64_t probes_solved;    /* truncated strong-branching LPs */
+    int64_t pivots;           /* tableau pivots of the node LPs (refactor + simplex) */
+    int64_t open_nodes;
+    int64_t created_nodes;    /* == next_node_idx */
+    int64_t steps;            /* frontier batches processed */
+    double primal_bound;      /* +inf while no incumbent */
+    double dual_bound;
+    double gap;               /* current_gap; -1 encodes None (no incumbent) */
+    double solve_seconds;     /* accumulated wall time inside mipx_tree_solve */
+    double kernel_ms;         /* accumulated HIP-event time of the node LP kernel */
+    int32_t status;           /* 0 unsolved, 1 optimal, 2 infeasible, 3 unbounded,
+                                 4 stopped on iterations or time */
+    int32_t has_solution;
+} mipx_tree_stats;
+
+/*
+ * branch_rule: 0 most fractional (BaseNode.branch, base_node.py:532-562),
+ *              1 pseudo cost with strong-branching initialisation (pseudo_cost.py:22-133)
+ * search_rule: 0 best first (BaseNode.__lt__, base_node.py:677-681), 1 depth first
+ *              (nodes/search/depth_first.py:24-28)
+ * l, u: root bounds; int_idx: integerIndices.  pool_capacity: node records kept in HBM.
+ */
+int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const double *l,
+                     const double *u, int branch_rule, int search_rule, int strong_branch_iters,
+                     int max_batch, int64_t pool_capacity, mipx_tree **out);
+void mipx_tree_destroy(mipx_tree *t);
+/* Run or continue the search (re-entrant like BranchAndBound.solve).  Limits <= 0 mean none.
+ * frontier_batch = 1 reproduces the reference's node order exactly. */
+int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max_seconds,
+                    int frontier_batch, int64_t max_steps, mipx_tree_stats *out);
+int mipx_tree_get_stats(mipx_tree *t, mipx_tree_stats *out);
+int mipx_tree_solution(mipx_tree *t, double *x);
+int mipx_tree_set_primal_bound(mipx_tree *t, double bound); /* initial_primal_bound / exchange */
+int mipx_tree_pseudo_costs(mipx_tree *t, double *cost_l, double *cost_r, int32_t *times_l,
+                           int32_t *times_r);
+/* Test hook: record (node id, LP status, branching variable or -1, objective) per evaluated
+ * node; mipx_tree_trace returns the number recorded and copies at most `capacity` of them. */
+int mipx_tree_set_trace(mipx_tree *t, int on);
+int64_t mipx_tree_trace(mipx_tree *t, int64_t capacity, int64_t *node_id, int32_t *lp_status,
+                        int32_t *branch_var, double *objective);
+
 /* Name of the kernel instantiation that (m, n) dispatches to, e.g. "lp_dual_simplex<16,32,8,8>". */
 int mipx_kernel_name(int m, int n, char *buf, size_t buflen);
 

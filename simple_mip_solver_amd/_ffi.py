@@ -21,6 +21,9 @@ SYMBOLS = [
     'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_dev_alloc', 'mipx_dev_free',
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
+    'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
+    'mipx_tree_solution', 'mipx_tree_set_primal_bound', 'mipx_tree_pseudo_costs',
+    'mipx_tree_set_trace', 'mipx_tree_trace',
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -33,6 +36,22 @@ _lib = None
 
 class MipxError(RuntimeError):
     pass
+
+
+class TreeStats(C.Structure):
+    """mipx_tree_stats (include/mipx.h)."""
+    _fields_ = [('evaluated_nodes', C.c_int64), ('lp_solved', C.c_int64),
+                ('probes_solved', C.c_int64), ('pivots', C.c_int64), ('open_nodes', C.c_int64),
+                ('created_nodes', C.c_int64), ('steps', C.c_int64), ('primal_bound', C.c_double),
+                ('dual_bound', C.c_double), ('gap', C.c_double), ('solve_seconds', C.c_double),
+                ('kernel_ms', C.c_double), ('status', C.c_int32), ('has_solution', C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+TREE_STATUS = {0: 'unsolved', 1: 'optimal', 2: 'infeasible', 3: 'unbounded',
+               4: 'stopped on iterations or time'}
 
 
 def lib():
@@ -67,6 +86,19 @@ def lib():
     L.mipx_timer_start.argtypes = [_vp]
     L.mipx_timer_stop.argtypes = [_vp, C.POINTER(C.c_float)]
     L.mipx_kernel_name.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.mipx_tree_create.argtypes = [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int64, C.POINTER(_vp)]
+    L.mipx_tree_destroy.argtypes = [_vp]
+    L.mipx_tree_destroy.restype = None
+    L.mipx_tree_solve.argtypes = [_vp, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_int64,
+                                  C.POINTER(TreeStats)]
+    L.mipx_tree_get_stats.argtypes = [_vp, C.POINTER(TreeStats)]
+    L.mipx_tree_solution.argtypes = [_vp, _vp]
+    L.mipx_tree_set_primal_bound.argtypes = [_vp, C.c_double]
+    L.mipx_tree_pseudo_costs.argtypes = [_vp, _vp, _vp, _vp, _vp]
+    L.mipx_tree_set_trace.argtypes = [_vp, C.c_int]
+    L.mipx_tree_trace.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, _vp]
+    L.mipx_tree_trace.restype = C.c_int64
     _lib = L
     return L
 
@@ -189,6 +221,84 @@ class Problem:
     def close(self):
         if getattr(self, '_h', None) and getattr(self.ctx, '_h', None):
             lib().mipx_problem_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Tree:
+    """Native frontier engine on one problem (mipx_tree)."""
+
+    def __init__(self, problem, integer_indices, l, u, branch_rule='most fractional',
+                 search_rule='best first', strong_branch_iters=5, max_batch=1,
+                 pool_capacity=1 << 16):
+        self.problem = problem
+        ints = np.ascontiguousarray(integer_indices, dtype=np.int32)
+        l = np.ascontiguousarray(l, dtype=np.float64).reshape(problem.n)
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(problem.n)
+        rule = {'most fractional': 0, 'pseudo cost': 1}[branch_rule]
+        search = {'best first': 0, 'depth first': 1}[search_rule]
+        h = _vp()
+        rc = lib().mipx_tree_create(problem._h, _ptr(ints), len(ints), _ptr(l), _ptr(u), rule,
+                                    search, int(strong_branch_iters), int(max_batch),
+                                    int(pool_capacity), C.byref(h))
+        problem.ctx.check(rc, 'mipx_tree_create')
+        self._h = h
+        self.max_batch = int(max_batch)
+
+    def solve(self, node_limit=0, mip_gap=1e-4, max_seconds=0.0, frontier_batch=None, max_steps=0):
+        st = TreeStats()
+        rc = lib().mipx_tree_solve(self._h, int(node_limit), float(mip_gap), float(max_seconds),
+                                   int(frontier_batch or self.max_batch), int(max_steps),
+                                   C.byref(st))
+        self.problem.ctx.check(rc, 'mipx_tree_solve')
+        return st.as_dict()
+
+    def stats(self):
+        st = TreeStats()
+        self.problem.ctx.check(lib().mipx_tree_get_stats(self._h, C.byref(st)), 'mipx_tree_get_stats')
+        return st.as_dict()
+
+    def solution(self):
+        x = np.zeros(self.problem.n)
+        self.problem.ctx.check(lib().mipx_tree_solution(self._h, _ptr(x)), 'mipx_tree_solution')
+        return x
+
+    def set_primal_bound(self, bound):
+        self.problem.ctx.check(lib().mipx_tree_set_primal_bound(self._h, float(bound)),
+                               'mipx_tree_set_primal_bound')
+
+    def pseudo_costs(self):
+        """The table in the reference's layout {idx: {'left'|'right': {'cost', 'times'}}}."""
+        n = self.problem.n
+        cl, cr = np.zeros(n), np.zeros(n)
+        tl, tr = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self.problem.ctx.check(lib().mipx_tree_pseudo_costs(self._h, _ptr(cl), _ptr(cr), _ptr(tl),
+                                                            _ptr(tr)), 'mipx_tree_pseudo_costs')
+        out = {}
+        for i in range(n):
+            if tl[i] or tr[i]:
+                out[i] = {'left': {'cost': float(cl[i]), 'times': int(tl[i])},
+                          'right': {'cost': float(cr[i]), 'times': int(tr[i])}}
+        return out
+
+    def set_trace(self, on=True):
+        self.problem.ctx.check(lib().mipx_tree_set_trace(self._h, int(on)), 'mipx_tree_set_trace')
+
+    def trace(self):
+        k = lib().mipx_tree_trace(self._h, 0, None, None, None, None)
+        ids = np.zeros(k, np.int64); st = np.zeros(k, np.int32)
+        bv = np.zeros(k, np.int32); obj = np.zeros(k)
+        lib().mipx_tree_trace(self._h, k, _ptr(ids), _ptr(st), _ptr(bv), _ptr(obj))
+        return dict(node_id=ids, status=st, branch_var=bv, objective=obj)
+
+    def close(self):
+        if getattr(self, '_h', None) and getattr(self.problem, '_h', None):
+            lib().mipx_tree_destroy(self._h)
         self._h = None
 
     def __del__(self):

@@ -19,7 +19,13 @@ from simple_mip_solver_amd.algorithms.base_algorithm import BaseAlgorithm
 from simple_mip_solver_amd.nodes.base_node import BaseNode
 from simple_mip_solver_amd.utils.binary_tree import BinaryTree
 
+from simple_mip_solver_amd.nodes.branch.pseudo_cost import PseudoCostBranchNode
+from simple_mip_solver_amd.nodes.search.depth_first import DepthFirstSearchNode
+from simple_mip_solver_amd.nodes.nodes import PseudoCostBranchDepthFirstSearchNode
+
 INF = float('inf')
+_NATIVE_NODES = (BaseNode, PseudoCostBranchNode, DepthFirstSearchNode,
+                 PseudoCostBranchDepthFirstSearchNode)
 
 
 def _leaf_value(node):
@@ -112,10 +118,29 @@ class BranchAndBound(BaseAlgorithm):
     _queue_funcs = ['put', 'get', 'empty']
 
     def __init__(self, model, Node=BaseNode, node_queue=None, node_limit=INF, mip_gap=.0001,
-                 logging=False, max_run_time=INF, initial_primal_bound=INF, **kwargs):
+                 logging=False, max_run_time=INF, initial_primal_bound=INF, frontier_batch=None,
+                 pool_capacity=1 << 16, **kwargs):
         """All problems are converted to minimisation with A x >= b on the way in.  **kwargs are
         handed to every bound()/branch() call and refreshed from what those calls return
-        (e.g. pseudo_costs={}, strong_branch_iters=5, gomory_cuts=False)."""
+        (e.g. pseudo_costs={}, strong_branch_iters=5, gomory_cuts=False).
+
+        frontier_batch (extension, default None = the reference's one-node-at-a-time Python
+        loop): run the whole search in the native frontier engine (mipx_tree_*), evaluating that
+        many open nodes per GPU step with node records resident in HBM.  Only for the stock node
+        classes, the default queue and gomory_cuts=False; frontier_batch=1 keeps the reference's
+        exact node order.  In this mode `tree` holds only the root (nodes live on the device)."""
+        self._native = None
+        self._native_stats = None
+        if frontier_batch is not None:
+            assert isinstance(frontier_batch, int) and frontier_batch > 0, \
+                'frontier_batch must be a positive integer'
+            assert node_queue is None, 'frontier_batch needs the default node queue'
+            assert Node in _NATIVE_NODES, \
+                'frontier_batch is only available for the stock node classes'
+            assert kwargs.get('gomory_cuts') is False, \
+                'frontier_batch needs gomory_cuts=False (cut rounds run on the per-node path)'
+        self.frontier_batch = frontier_batch
+        self._pool_capacity = pool_capacity
         node_queue = node_queue or PriorityQueue()
         super().__init__(model=model, Node=Node, node_attributes=self._node_attributes,
                          node_funcs=self._node_funcs, **kwargs)
@@ -152,6 +177,8 @@ class BranchAndBound(BaseAlgorithm):
 
     @property
     def dual_bound(self):
+        if self._native_stats is not None:
+            return self._native_stats['dual_bound']
         return self._leaf_bounds.minimum()
 
     @property
@@ -173,6 +200,8 @@ class BranchAndBound(BaseAlgorithm):
     def solve(self):
         """Run (or continue) the search until the queue empties, the problem proves unbounded, or
         the node / gap / time limit is hit (reference :215-241)."""
+        if self.frontier_batch is not None:
+            return self._solve_native()
         start = time.perf_counter()
         if self.status == 'unsolved':
             self._node_queue.put(self.root_node)
@@ -195,6 +224,43 @@ class BranchAndBound(BaseAlgorithm):
             self.status = 'stopped on iterations or time'
         self.solution = self._best_solution
         self.objective_value = self.primal_bound
+
+    def _solve_native(self):
+        """The same search, run by the native frontier engine (include/mipx.h mipx_tree_*)."""
+        from simple_mip_solver_amd import _ffi
+        from simple_mip_solver_amd.lp import get_backend, HipBackend
+        if self._native is None:
+            backend = get_backend()
+            assert isinstance(backend, HipBackend), 'frontier_batch needs the HIP backend'
+            lp = self.root_node.lp
+            rs = lp._engine_form()
+            problem = backend._problem(rs.A, rs.b, rs.c, rs.key)
+            l, u = lp._bounds()
+            pseudo = issubclass(self._Node, PseudoCostBranchNode)
+            self._native = _ffi.Tree(
+                problem, self.model.integerIndices, l, u,
+                branch_rule='pseudo cost' if pseudo else 'most fractional',
+                search_rule=self.root_node.search_method,
+                strong_branch_iters=self._kwargs.get('strong_branch_iters', 5),
+                max_batch=self.frontier_batch, pool_capacity=self._pool_capacity)
+            if self.primal_bound < INF:
+                self._native.set_primal_bound(self.primal_bound)
+        st = self._native.solve(node_limit=0 if self.node_limit == INF else self.node_limit,
+                                mip_gap=self.mip_gap,
+                                max_seconds=0.0 if self.max_run_time == INF else self.max_run_time,
+                                frontier_batch=self.frontier_batch)
+        self._native_stats = st
+        self.solve_time = st['solve_seconds']
+        self.evaluated_nodes = st['evaluated_nodes']
+        self.primal_bound = st['primal_bound']
+        self.status = _ffi.TREE_STATUS[st['status']]
+        self._unbounded = True if st['status'] == 3 else self._unbounded
+        self._best_solution = self._native.solution() if st['has_solution'] else None
+        self.solution = self._best_solution
+        self.objective_value = self.primal_bound
+        self._kwargs['next_node_idx'] = st['created_nodes']
+        if issubclass(self._Node, PseudoCostBranchNode):
+            self._kwargs['pseudo_costs'] = self._native.pseudo_costs()
 
     def _evaluate_node(self, node):
         """Bound the node unless its inherited bound already prunes it; record an incumbent or

@@ -36,6 +36,7 @@ struct LpArgs {
     const double *A, *b, *c;       // shared by the batch
     const double *l, *u;           // batch x n
     const int8_t *vstat_in;        // batch x (n+m) or nullptr
+    const int32_t *slot;           // optional: node k reads l/u/vstat_in at row slot[k] (node pool)
     int max_iter;
     int32_t *status;
     double *obj;
@@ -158,9 +159,10 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
     if (node >= g.batch) return;
     {
         double T[R][C];
-        const double *lk = g.l + (size_t)node * n;
-        const double *uk = g.u + (size_t)node * n;
-        const int8_t *vin = g.vstat_in ? g.vstat_in + (size_t)node * nv : nullptr;
+        const size_t src = g.slot ? (size_t)g.slot[node] : (size_t)node;
+        const double *lk = g.l + src * n;
+        const double *uk = g.u + src * n;
+        const int8_t *vin = g.vstat_in ? g.vstat_in + src * nv : nullptr;
 
         // ---- 0. T = -A, beta0 = -b, d = c, slack basis -------------------------------------
 #pragma unroll

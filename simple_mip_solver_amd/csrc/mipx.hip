@@ -79,6 +79,8 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
 
+#include "tree_engine.hip.h"
+
 extern "C" {
 
 int mipx_abi_version(void) { return 1; }
@@ -183,7 +185,7 @@ int mipx_lp_solve_batch_dev(mipx_problem *p, int batch, const double *l, const d
     mipx::LpArgs a;
     a.m = p->m; a.n = p->n;
     a.A = p->dA; a.b = p->db; a.c = p->dc;
-    a.l = l; a.u = u; a.vstat_in = vstat_in; a.max_iter = max_iter;
+    a.l = l; a.u = u; a.vstat_in = vstat_in; a.slot = nullptr; a.max_iter = max_iter;
     a.status = status; a.obj = obj; a.x = x; a.y = y; a.vstat_out = vstat_out;
     a.iters = iters; a.npivots = npivots; a.batch = batch;
     a.dbg_T = p->dbg_T; a.dbg_vec = p->dbg_vec; a.dbg_idx = p->dbg_idx;

@@ -1,0 +1,589 @@
+// tree_engine.hip.h -- native frontier engine: the BranchAndBound.solve() loop of the reference
+// (simple_mip_solver/algorithms/branch_and_bound.py:215-266) with the stock node classes
+// (BaseNode / PseudoCostBranchNode, best-first or depth-first), processing a BATCH of open nodes
+// per step on the GPU.  Node records (bounds + warm-start basis) live in a device-resident pool;
+// the host keeps only the priority queue and 48 bytes of bookkeeping per node.
+//
+// frontier_batch = 1 reproduces the reference's node order exactly (the queue is a re-statement of
+// CPython's heapq, which queue.PriorityQueue uses), including pseudo-cost table evolution; larger
+// batches evaluate the B best open nodes per step against the table as of the start of the step.
+// Included by mipx.hip (needs mipx_ctx, mipx_problem, pick_cfg, HIP_TRY, fail).
+#pragma once
+#include <chrono>
+#include <cmath>
+#include <limits>
+#include <queue>
+
+#include "tree_kernels.hip.h"
+
+struct NodeRec {
+    double key;          // queue key: dual bound (best first) or -depth (depth first)
+    double dual_bound;   // bound inherited from the parent (parent's LP objective)
+    double b_val;
+    int32_t slot;        // row in the device pool, -1 once released
+    int32_t depth;
+    int32_t b_idx;       // variable branched on to create this node (-1 root)
+    int32_t b_dir;       // 0 left (x <= floor), 1 right (x >= ceil)
+};
+
+// CPython's heapq on node ids (Lib/heapq.py heappush/heappop/_siftdown/_siftup), so that ties are
+// broken exactly as queue.PriorityQueue breaks them in the reference.
+struct PyHeap {
+    std::vector<int64_t> h;
+    const std::vector<NodeRec> *nodes = nullptr;
+    bool lt(int64_t a, int64_t b) const { return (*nodes)[a].key < (*nodes)[b].key; }
+    void siftdown(size_t startpos, size_t pos) {
+        const int64_t item = h[pos];
+        while (pos > startpos) {
+            const size_t parent = (pos - 1) >> 1;
+            if (lt(item, h[parent])) { h[pos] = h[parent]; pos = parent; continue; }
+            break;
+        }
+        h[pos] = item;
+    }
+    void siftup(size_t pos) {
+        const size_t end = h.size(), start = pos;
+        const int64_t item = h[pos];
+        size_t child = 2 * pos + 1;
+        while (child < end) {
+            const size_t right = child + 1;
+            if (right < end && !lt(h[child], h[right])) child = right;
+            h[pos] = h[child];
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        h[pos] = item;
+        siftdown(start, pos);
+    }
+    void push(int64_t id) { h.push_back(id); siftdown(0, h.size() - 1); }
+    int64_t pop() {
+        const int64_t last = h.back();
+        h.pop_back();
+        if (h.empty()) return last;
+        const int64_t top = h[0];
+        h[0] = last;
+        siftup(0);
+        return top;
+    }
+    bool empty() const { return h.empty(); }
+    size_t size() const { return h.size(); }
+};
+
+struct mipx_tree {
+    mipx_problem *prob = nullptr;
+    mipx_ctx *ctx = nullptr;
+    int n = 0, m = 0, n_int = 0;
+    int rule = 0, search = 0, sb_iters = 5, max_batch = 1;
+    int64_t capacity = 0;
+    std::vector<int32_t> int_idx;
+    // device pool + per-step buffers
+    double *pool_l = nullptr, *pool_u = nullptr;
+    int8_t *pool_v = nullptr;
+    int32_t *d_int_idx = nullptr, *d_slot = nullptr, *d_status = nullptr, *d_iters = nullptr,
+            *d_npiv = nullptr, *d_bidx = nullptr, *d_mipf = nullptr, *d_nprobe = nullptr,
+            *d_plist = nullptr, *d_pairs = nullptr;
+    double *d_obj = nullptr, *d_x = nullptr, *d_cost_l = nullptr, *d_cost_r = nullptr;
+    int8_t *d_vout = nullptr;
+    uint8_t *d_has = nullptr;
+    // probe pool (strong branching)
+    int64_t probe_cap = 0;
+    double *pp_l = nullptr, *pp_u = nullptr, *pp_obj = nullptr;
+    int8_t *pp_v = nullptr;
+    int32_t *pp_status = nullptr;
+    // host state
+    std::vector<NodeRec> nodes;
+    std::vector<int32_t> free_slots;
+    PyHeap heap;
+    std::priority_queue<std::pair<double, int64_t>, std::vector<std::pair<double, int64_t>>,
+                        std::greater<std::pair<double, int64_t>>> open_bounds;  // lazy, for DFS
+    std::vector<uint8_t> is_open;
+    double closed_min = std::numeric_limits<double>::infinity();
+    double primal = std::numeric_limits<double>::infinity();
+    std::vector<double> best_x;
+    bool have_x = false, unbounded = false, started = false;
+    int status = 0;  // 0 unsolved, 1 optimal, 2 infeasible, 3 unbounded, 4 stopped
+    int64_t evaluated = 0, lps = 0, probes = 0, pivots = 0, steps = 0;
+    double solve_seconds = 0.0, kernel_ms = 0.0;
+    std::vector<double> cost_l, cost_r;
+    std::vector<int32_t> times_l, times_r;
+    std::vector<uint8_t> has_entry;
+    // trace of evaluated nodes: id, lp status, branch variable, objective
+    std::vector<int64_t> tr_id;
+    std::vector<int32_t> tr_status, tr_bidx;
+    std::vector<double> tr_obj;
+    bool trace = false;
+};
+
+namespace {
+
+template <typename T>
+int dmalloc(mipx_ctx *ctx, T **p, size_t count) {
+    HIP_TRY(ctx, hipMalloc((void **)p, (count ? count : 1) * sizeof(T)));
+    return MIPX_OK;
+}
+
+double tree_open_min(mipx_tree *t) {
+    const double inf = std::numeric_limits<double>::infinity();
+    if (t->search == 0) return t->heap.empty() ? inf : t->nodes[t->heap.h[0]].dual_bound;
+    while (!t->open_bounds.empty() && !t->is_open[t->open_bounds.top().second]) t->open_bounds.pop();
+    return t->open_bounds.empty() ? inf : t->open_bounds.top().first;
+}
+
+double tree_dual_bound(mipx_tree *t) { return std::fmin(tree_open_min(t), t->closed_min); }
+
+// reference current_gap (branch_and_bound.py:203-213); -1 encodes None
+double tree_gap(mipx_tree *t) {
+    const double inf = std::numeric_limits<double>::infinity();
+    const double p = t->primal, d = tree_dual_bound(t);
+    if (p == 0 && d == 0) return 0.0;
+    if (p == 0) return inf;
+    if (p == inf) return -1.0;
+    return std::fabs(p - d) / std::fabs(p);
+}
+
+void tree_push(mipx_tree *t, int64_t id) {
+    t->heap.push(id);
+    if ((size_t)id >= t->is_open.size()) t->is_open.resize(id + 1, 0);
+    t->is_open[id] = 1;
+    if (t->search != 0) t->open_bounds.push({t->nodes[id].dual_bound, id});
+}
+
+int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const int8_t *v,
+              const int32_t *slot, int max_iter, int32_t *status, double *obj, double *x,
+              int8_t *vout, int32_t *iters, int32_t *npiv) {
+    mipx_ctx *ctx = t->ctx;
+    const KernelCfg *cfg = pick_cfg(t->m, t->n);
+    mipx::LpArgs a;
+    a.m = t->m; a.n = t->n;
+    a.A = t->prob->dA; a.b = t->prob->db; a.c = t->prob->dc;
+    a.l = l; a.u = u; a.vstat_in = v; a.slot = slot; a.max_iter = max_iter;
+    a.status = status; a.obj = obj; a.x = x; a.y = nullptr; a.vstat_out = vout;
+    a.iters = iters; a.npivots = npiv; a.batch = batch;
+    a.dbg_T = nullptr; a.dbg_vec = nullptr; a.dbg_idx = nullptr;
+    cfg->launch(a, batch, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return MIPX_OK;
+}
+
+int launch_score(mipx_tree *t, int batch) {
+    mipx::ScoreArgs s;
+    s.n = t->n; s.n_int = t->n_int; s.batch = batch; s.rule = t->rule;
+    s.int_idx = t->d_int_idx; s.x = t->d_x; s.status = t->d_status;
+    s.cost_l = t->d_cost_l; s.cost_r = t->d_cost_r; s.has_entry = t->d_has;
+    s.branch_idx = t->d_bidx; s.mip_feasible = t->d_mipf; s.n_probe = t->d_nprobe;
+    s.probe_list = t->d_plist;
+    hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, t->ctx->stream, s);
+    HIP_TRY(t->ctx, hipGetLastError());
+    return MIPX_OK;
+}
+
+// pseudo_cost.py:68-100
+void pc_update(mipx_tree *t, int var, int dir, int lp_status, double objective, double dual_bound,
+               double variable_change) {
+    double &cost = dir ? t->cost_r[var] : t->cost_l[var];
+    int32_t &times = dir ? t->times_r[var] : t->times_l[var];
+    if (lp_status == 0 || lp_status == 3) {
+        double bc = objective - dual_bound;
+        if (bc < 0) bc = 0;
+        cost = (cost * (double)times + bc / variable_change) / (double)(times + 1);
+    }
+    times += 1;
+    t->has_entry[var] = 1;
+}
+
+int tree_step(mipx_tree *t, int want) {
+    mipx_ctx *ctx = t->ctx;
+    const int n = t->n, nv = t->n + t->m;
+    const double inf = std::numeric_limits<double>::infinity();
+    hipStream_t st = ctx->stream;
+    // 1. pop the batch (a node whose inherited bound cannot beat the incumbent is closed unevaluated)
+    std::vector<int64_t> ids;
+    std::vector<int32_t> slots;
+    while ((int)ids.size() < want && !t->heap.empty()) {
+        const int64_t id = t->heap.pop();
+        t->is_open[id] = 0;
+        NodeRec &nd = t->nodes[id];
+        if (!(nd.dual_bound < t->primal)) {
+            t->closed_min = std::fmin(t->closed_min, nd.dual_bound);
+            t->free_slots.push_back(nd.slot);
+            nd.slot = -1;
+            continue;
+        }
+        ids.push_back(id);
+        slots.push_back(nd.slot);
+    }
+    const int B = (int)ids.size();
+    if (B == 0) return MIPX_OK;
+    t->steps++;
+    HIP_TRY(ctx, hipMemcpyAsync(t->d_slot, slots.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    // 2. LP relaxations + scoring
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
+    int rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, t->d_slot, 0, t->d_status, t->d_obj,
+                       t->d_x, t->d_vout, t->d_iters, t->d_npiv);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+    if ((rc = launch_score(t, B))) return rc;
+    std::vector<int32_t> status(B), bidx(B), mipf(B), nprobe(B), npiv(B);
+    std::vector<double> obj(B);
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) t->kernel_ms += ms;
+    }
+    HIP_TRY(ctx, hipMemcpy(status.data(), t->d_status, (size_t)B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(obj.data(), t->d_obj, (size_t)B * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(bidx.data(), t->d_bidx, (size_t)B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(mipf.data(), t->d_mipf, (size_t)B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(nprobe.data(), t->d_nprobe, (size_t)B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(npiv.data(), t->d_npiv, (size_t)B * 4, hipMemcpyDeviceToHost));
+    t->lps += B;
+    for (int k = 0; k < B; k++) t->pivots += npiv[k];
+
+    // 3. pseudo costs: strong-branch initialisation + the update for the branch that made the node
+    if (t->rule == 1) {
+        int64_t total = 0;
+        for (int k = 0; k < B; k++) total += nprobe[k];
+        std::vector<int32_t> plist, pair_pos, pair_var, pair_slot, child_slot;
+        std::vector<double> xrow;  // x of the probed variables
+        std::vector<int32_t> pst;
+        std::vector<double> pobj;
+        if (total > 0) {
+            if (2 * total > t->probe_cap) return fail(ctx, MIPX_ENOMEM, "tree: probe pool exhausted");
+            plist.resize((size_t)B * t->n_int);
+            HIP_TRY(ctx, hipMemcpy(plist.data(), t->d_plist, plist.size() * 4, hipMemcpyDeviceToHost));
+            for (int k = 0; k < B; k++)
+                for (int e = 0; e < nprobe[k]; e++) {
+                    pair_pos.push_back(k);
+                    pair_slot.push_back(slots[k]);
+                    pair_var.push_back(t->int_idx[plist[(size_t)k * t->n_int + e]]);
+                }
+            const int P = (int)pair_pos.size();
+            child_slot.resize(2 * (size_t)P);
+            for (int c = 0; c < 2 * P; c++) child_slot[c] = c;
+            // d_pairs layout: [parent_slot | parent_pos | var | child_slot(2P)]
+            HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs, pair_slot.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs + P, pair_pos.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs + 2 * P, pair_var.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs + 3 * P, child_slot.data(), (size_t)P * 8, hipMemcpyHostToDevice, st));
+            mipx::ChildArgs ca;
+            ca.n = n; ca.m = t->m; ca.count = P;
+            ca.src_l = t->pool_l; ca.src_u = t->pool_u;
+            ca.parent_slot = t->d_pairs; ca.parent_pos = t->d_pairs + P; ca.var = t->d_pairs + 2 * P;
+            ca.x = t->d_x; ca.vstat = t->d_vout;
+            ca.dst_l = t->pp_l; ca.dst_u = t->pp_u; ca.dst_v = t->pp_v;
+            ca.child_slot = t->d_pairs + 3 * P;
+            hipLaunchKernelGGL(mipx::make_children, dim3(2 * P), dim3(256), 0, st, ca);
+            HIP_TRY(ctx, hipGetLastError());
+            // truncated dual simplex on every probe (base_node.py:645-646)
+            rc = launch_lp(t, 2 * P, t->pp_l, t->pp_u, t->pp_v, nullptr, t->sb_iters, t->pp_status,
+                           t->pp_obj, nullptr, nullptr, nullptr, nullptr);
+            if (rc) return rc;
+            pst.resize(2 * (size_t)P);
+            pobj.resize(2 * (size_t)P);
+            xrow.resize(P);
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            HIP_TRY(ctx, hipMemcpy(pst.data(), t->pp_status, pst.size() * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(pobj.data(), t->pp_obj, pobj.size() * 8, hipMemcpyDeviceToHost));
+            for (int e = 0; e < P; e++)
+                HIP_TRY(ctx, hipMemcpy(&xrow[e], t->d_x + (size_t)pair_pos[e] * n + pair_var[e], 8,
+                                       hipMemcpyDeviceToHost));
+            t->probes += 2 * P;
+        }
+        // table updates in the reference's order: node by node; per node its probes (ascending
+        // integer index, left then right), then its own branch unless just initialised
+        size_t e = 0;
+        bool changed = false;
+        for (int k = 0; k < B; k++) {
+            const bool lp_feasible = status[k] == 0 || status[k] == 2;
+            const NodeRec &nd = t->nodes[ids[k]];
+            bool own_probed = false;
+            if (lp_feasible) {
+                for (int q = 0; q < nprobe[k]; q++, e++) {
+                    const int var = pair_var[e];
+                    const double bv = xrow[e];
+                    pc_update(t, var, 0, pst[2 * e], pobj[2 * e], obj[k], bv - std::floor(bv));
+                    pc_update(t, var, 1, pst[2 * e + 1], pobj[2 * e + 1], obj[k], std::ceil(bv) - bv);
+                    if (var == nd.b_idx) own_probed = true;
+                    changed = true;
+                }
+                if (nd.b_idx >= 0 && !own_probed) {
+                    // variable_change: b_val - u[b_idx] (left) or l[b_idx] - b_val (right)
+                    const double vc = nd.b_dir == 0 ? nd.b_val - std::floor(nd.b_val)
+                                                    : std::ceil(nd.b_val) - nd.b_val;
+                    pc_update(t, nd.b_idx, nd.b_dir, status[k], obj[k], nd.dual_bound, vc);
+                    changed = true;
+                }
+            } else {
+                e += 0;
+            }
+        }
+        if (changed) {
+            HIP_TRY(ctx, hipMemcpyAsync(t->d_cost_l, t->cost_l.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(t->d_cost_r, t->cost_r.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(t->d_has, t->has_entry.data(), (size_t)n, hipMemcpyHostToDevice, st));
+            if ((rc = launch_score(t, B))) return rc;
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            HIP_TRY(ctx, hipMemcpy(bidx.data(), t->d_bidx, (size_t)B * 4, hipMemcpyDeviceToHost));
+        }
+    }
+
+    // 4. the reference's _evaluate_node bookkeeping, node by node
+    std::vector<int32_t> br_pos, br_slot, br_var, br_child;
+    int incumbent_pos = -1;
+    for (int k = 0; k < B; k++) {
+        const int64_t id = ids[k];
+        t->evaluated++;
+        const bool lp_feasible = status[k] == 0 || status[k] == 2;
+        if (status[k] == 2) t->unbounded = true;
+        int branched_on = -1;
+        double leaf_value = lp_feasible ? obj[k] : inf;
+        if (lp_feasible && obj[k] < t->primal) {
+            if (mipf[k]) {
+                t->primal = obj[k];
+                incumbent_pos = k;
+            } else if (bidx[k] >= 0) {
+                if (t->free_slots.size() < 2) return fail(ctx, MIPX_ENOMEM, "tree: node pool exhausted");
+                branched_on = bidx[k];
+                double xv;
+                HIP_TRY(ctx, hipMemcpy(&xv, t->d_x + (size_t)k * n + branched_on, 8, hipMemcpyDeviceToHost));
+                for (int dir = 0; dir < 2; dir++) {
+                    NodeRec c;
+                    c.dual_bound = obj[k];
+                    c.depth = t->nodes[id].depth + 1;
+                    c.key = t->search == 0 ? c.dual_bound : -(double)c.depth;
+                    c.b_idx = branched_on; c.b_dir = dir; c.b_val = xv;
+                    c.slot = t->free_slots.back();
+                    t->free_slots.pop_back();
+                    br_child.push_back(c.slot);
+                    t->nodes.push_back(c);
+                    tree_push(t, (int64_t)t->nodes.size() - 1);
+                }
+                br_pos.push_back(k);
+                br_slot.push_back(slots[k]);
+                br_var.push_back(branched_on);
+                leaf_value = inf;  // no longer a leaf
+            }
+        }
+        if (branched_on < 0) t->closed_min = std::fmin(t->closed_min, leaf_value);
+        if (t->trace) {
+            t->tr_id.push_back(id); t->tr_status.push_back(status[k]);
+            t->tr_bidx.push_back(branched_on); t->tr_obj.push_back(obj[k]);
+        }
+    }
+    if (incumbent_pos >= 0) {
+        // the last improving node of the batch holds the incumbent
+        HIP_TRY(ctx, hipMemcpy(t->best_x.data(), t->d_x + (size_t)incumbent_pos * n, (size_t)n * 8,
+                               hipMemcpyDeviceToHost));
+        t->have_x = true;
+    }
+    // 5. children records on the device, then release the evaluated nodes' rows
+    const int P = (int)br_pos.size();
+    if (P > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs, br_slot.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs + P, br_pos.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs + 2 * P, br_var.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs + 3 * P, br_child.data(), (size_t)P * 8, hipMemcpyHostToDevice, st));
+        mipx::ChildArgs ca;
+        ca.n = n; ca.m = t->m; ca.count = P;
+        ca.src_l = t->pool_l; ca.src_u = t->pool_u;
+        ca.parent_slot = t->d_pairs; ca.parent_pos = t->d_pairs + P; ca.var = t->d_pairs + 2 * P;
+        ca.x = t->d_x; ca.vstat = t->d_vout;
+        ca.dst_l = t->pool_l; ca.dst_u = t->pool_u; ca.dst_v = t->pool_v;
+        ca.child_slot = t->d_pairs + 3 * P;
+        hipLaunchKernelGGL(mipx::make_children, dim3(2 * P), dim3(256), 0, st, ca);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(st));  // the staging vectors above die with this scope
+    }
+    for (int k = 0; k < B; k++) {
+        t->free_slots.push_back(slots[k]);
+        t->nodes[ids[k]].slot = -1;
+    }
+    (void)nv;
+    return MIPX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const double *l,
+                     const double *u, int branch_rule, int search_rule, int strong_branch_iters,
+                     int max_batch, int64_t pool_capacity, mipx_tree **out) {
+    if (!p || !out || n_int < 0 || (n_int && !int_idx) || !l || !u || max_batch < 1 ||
+        branch_rule < 0 || branch_rule > 1 || search_rule < 0 || search_rule > 1 ||
+        strong_branch_iters < 1)
+        return fail(p ? p->ctx : nullptr, MIPX_EINVAL, "mipx_tree_create: bad argument");
+    mipx_ctx *ctx = p->ctx;
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    mipx_tree *t = new (std::nothrow) mipx_tree();
+    if (!t) return fail(ctx, MIPX_ENOMEM, "mipx_tree_create: host alloc");
+    t->prob = p; t->ctx = ctx; t->n = p->n; t->m = p->m; t->n_int = n_int;
+    t->rule = branch_rule; t->search = search_rule; t->sb_iters = strong_branch_iters;
+    t->max_batch = max_batch;
+    t->capacity = pool_capacity > 2 * (int64_t)max_batch + 2 ? pool_capacity : 2 * (int64_t)max_batch + 2;
+    t->int_idx.assign(int_idx, int_idx + n_int);
+    for (int i = 0; i < n_int; i++)
+        if (int_idx[i] < 0 || int_idx[i] >= t->n) { delete t; return fail(ctx, MIPX_EINVAL, "mipx_tree_create: integer index out of range"); }
+    const size_t n = t->n, nv = t->n + t->m, cap = (size_t)t->capacity, B = (size_t)max_batch;
+    t->probe_cap = 2 * (int64_t)B * (n_int ? n_int : 1);
+    if (t->probe_cap > (int64_t)1 << 22) t->probe_cap = (int64_t)1 << 22;
+    const size_t pc = (size_t)t->probe_cap;
+    int rc = 0;
+    rc |= dmalloc(ctx, &t->pool_l, cap * n); rc |= dmalloc(ctx, &t->pool_u, cap * n);
+    rc |= dmalloc(ctx, &t->pool_v, cap * nv);
+    rc |= dmalloc(ctx, &t->d_int_idx, (size_t)n_int); rc |= dmalloc(ctx, &t->d_slot, B);
+    rc |= dmalloc(ctx, &t->d_status, B); rc |= dmalloc(ctx, &t->d_iters, B);
+    rc |= dmalloc(ctx, &t->d_npiv, B); rc |= dmalloc(ctx, &t->d_bidx, B);
+    rc |= dmalloc(ctx, &t->d_mipf, B); rc |= dmalloc(ctx, &t->d_nprobe, B);
+    rc |= dmalloc(ctx, &t->d_plist, B * (size_t)(n_int ? n_int : 1));
+    rc |= dmalloc(ctx, &t->d_pairs, 5 * (pc / 2 > B ? pc / 2 : B));
+    rc |= dmalloc(ctx, &t->d_obj, B); rc |= dmalloc(ctx, &t->d_x, B * n);
+    rc |= dmalloc(ctx, &t->d_vout, B * nv);
+    rc |= dmalloc(ctx, &t->d_cost_l, n); rc |= dmalloc(ctx, &t->d_cost_r, n);
+    rc |= dmalloc(ctx, &t->d_has, n);
+    if (branch_rule == 1) {
+        rc |= dmalloc(ctx, &t->pp_l, pc * n); rc |= dmalloc(ctx, &t->pp_u, pc * n);
+        rc |= dmalloc(ctx, &t->pp_v, pc * nv); rc |= dmalloc(ctx, &t->pp_obj, pc);
+        rc |= dmalloc(ctx, &t->pp_status, pc);
+    }
+    if (rc) { mipx_tree_destroy(t); return MIPX_EHIP; }
+    t->cost_l.assign(n, 0.0); t->cost_r.assign(n, 0.0);
+    t->times_l.assign(n, 0); t->times_r.assign(n, 0);
+    t->has_entry.assign(n, 0);
+    t->best_x.assign(n, 0.0);
+    HIP_TRY(ctx, hipMemcpy(t->d_int_idx, int_idx, (size_t)n_int * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(t->d_cost_l, 0, n * 8));
+    HIP_TRY(ctx, hipMemset(t->d_cost_r, 0, n * 8));
+    HIP_TRY(ctx, hipMemset(t->d_has, 0, n));
+    // root record in slot 0: cold start (all status codes 0 -> slack basis, sides from d_j)
+    HIP_TRY(ctx, hipMemcpy(t->pool_l, l, n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(t->pool_u, u, n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(t->pool_v, 0, nv));
+    t->free_slots.reserve(cap);
+    for (int64_t s = (int64_t)cap - 1; s >= 1; s--) t->free_slots.push_back((int32_t)s);
+    NodeRec root;
+    root.dual_bound = -std::numeric_limits<double>::infinity();
+    root.depth = 0; root.key = search_rule == 0 ? root.dual_bound : 0.0;
+    root.b_idx = -1; root.b_dir = 0; root.b_val = 0.0; root.slot = 0;
+    t->nodes.push_back(root);
+    t->heap.nodes = &t->nodes;
+    *out = t;
+    return MIPX_OK;
+}
+
+void mipx_tree_destroy(mipx_tree *t) {
+    if (!t) return;
+    if (t->ctx) (void)hipSetDevice(t->ctx->device);
+    void *ptrs[] = {t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_slot, t->d_status, t->d_iters,
+                    t->d_npiv, t->d_bidx, t->d_mipf, t->d_nprobe, t->d_plist, t->d_pairs, t->d_obj,
+                    t->d_x, t->d_vout, t->d_cost_l, t->d_cost_r, t->d_has, t->pp_l, t->pp_u, t->pp_v,
+                    t->pp_obj, t->pp_status};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    delete t;
+}
+
+int mipx_tree_set_trace(mipx_tree *t, int on) {
+    if (!t) return MIPX_EINVAL;
+    t->trace = on != 0;
+    return MIPX_OK;
+}
+
+int mipx_tree_set_primal_bound(mipx_tree *t, double bound) {
+    if (!t) return MIPX_EINVAL;
+    t->primal = bound;
+    return MIPX_OK;
+}
+
+/*
+ * Run (or continue) the search; mirrors BranchAndBound.solve (branch_and_bound.py:215-241).
+ * node_limit <= 0 and max_seconds <= 0 and max_steps <= 0 mean "no limit".
+ */
+int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max_seconds,
+                    int frontier_batch, int64_t max_steps, mipx_tree_stats *out) {
+    if (!t || frontier_batch < 1 || frontier_batch > t->max_batch)
+        return fail(t ? t->ctx : nullptr, MIPX_EINVAL, "mipx_tree_solve: bad argument");
+    mipx_ctx *ctx = t->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    const double inf = std::numeric_limits<double>::infinity();
+    if (!t->started) {
+        t->started = true;
+        tree_push(t, 0);
+    }
+    int64_t steps = 0;
+    for (;;) {
+        if (t->heap.empty() || t->unbounded) break;
+        if (node_limit > 0 && t->evaluated >= node_limit) break;
+        const double gap = tree_gap(t);
+        if (gap >= 0 && gap <= mip_gap) break;
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (max_seconds > 0 && el > max_seconds) break;
+        if (max_steps > 0 && steps >= max_steps) break;
+        int want = frontier_batch;
+        if (node_limit > 0 && node_limit - t->evaluated < want) want = (int)(node_limit - t->evaluated);
+        const int rc = tree_step(t, want);
+        if (rc) return rc;
+        steps++;
+    }
+    t->solve_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double gap = tree_gap(t);
+    if (t->unbounded) t->status = 3;
+    else if (t->heap.empty() && t->primal == inf) t->status = 2;
+    else if (t->primal < inf && gap >= 0 && gap <= mip_gap) t->status = 1;
+    else t->status = 4;
+    if (out) return mipx_tree_get_stats(t, out);
+    return MIPX_OK;
+}
+
+int mipx_tree_get_stats(mipx_tree *t, mipx_tree_stats *out) {
+    if (!t || !out) return MIPX_EINVAL;
+    out->evaluated_nodes = t->evaluated;
+    out->lp_solved = t->lps;
+    out->probes_solved = t->probes;
+    out->pivots = t->pivots;
+    out->open_nodes = (int64_t)t->heap.size();
+    out->created_nodes = (int64_t)t->nodes.size();
+    out->steps = t->steps;
+    out->primal_bound = t->primal;
+    out->dual_bound = tree_dual_bound(t);
+    out->gap = tree_gap(t);
+    out->solve_seconds = t->solve_seconds;
+    out->kernel_ms = t->kernel_ms;
+    out->status = t->status;
+    out->has_solution = t->have_x ? 1 : 0;
+    return MIPX_OK;
+}
+
+int mipx_tree_solution(mipx_tree *t, double *x) {
+    if (!t || !x) return MIPX_EINVAL;
+    if (!t->have_x) return fail(t->ctx, MIPX_EINVAL, "mipx_tree_solution: no incumbent");
+    std::memcpy(x, t->best_x.data(), (size_t)t->n * 8);
+    return MIPX_OK;
+}
+
+int mipx_tree_pseudo_costs(mipx_tree *t, double *cost_l, double *cost_r, int32_t *times_l,
+                           int32_t *times_r) {
+    if (!t || !cost_l || !cost_r || !times_l || !times_r) return MIPX_EINVAL;
+    std::memcpy(cost_l, t->cost_l.data(), (size_t)t->n * 8);
+    std::memcpy(cost_r, t->cost_r.data(), (size_t)t->n * 8);
+    std::memcpy(times_l, t->times_l.data(), (size_t)t->n * 4);
+    std::memcpy(times_r, t->times_r.data(), (size_t)t->n * 4);
+    return MIPX_OK;
+}
+
+int64_t mipx_tree_trace(mipx_tree *t, int64_t capacity, int64_t *node_id, int32_t *lp_status,
+                        int32_t *branch_var, double *objective) {
+    if (!t) return MIPX_EINVAL;
+    const int64_t k = (int64_t)t->tr_id.size() < capacity ? (int64_t)t->tr_id.size() : capacity;
+    for (int64_t i = 0; i < k; i++) {
+        if (node_id) node_id[i] = t->tr_id[i];
+        if (lp_status) lp_status[i] = t->tr_status[i];
+        if (branch_var) branch_var[i] = t->tr_bidx[i];
+        if (objective) objective[i] = t->tr_obj[i];
+    }
+    return (int64_t)t->tr_id.size();
+}
+
+}  // extern "C"

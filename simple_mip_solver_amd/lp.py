@@ -228,6 +228,7 @@ class DenseLP:
         self._row_status = None   # Clp codes per row
         self._rowset = None       # cached engine form of the rows
         self._rowmap = None       # (constraint index, row in block, sign) per engine row
+        self._solved_sig = None   # what the stored optimal solution belongs to (see dual())
 
     # ---- model building ------------------------------------------------------------------
     def addVariable(self, name, dim):
@@ -399,9 +400,17 @@ class DenseLP:
         l, u = self._bounds()
         assert np.all(np.isfinite(l)), 'the engine needs finite lower bounds (x >= 0 on the hot path)'
         max_iter = int(self.maxNumIteration) if self.maxNumIteration else 0
+        # Re-solving an LP that has not changed since it was solved to optimality (same rows,
+        # bounds and basis) is a no-op: the reference does exactly that once per fractional node
+        # when a cut round adds nothing (base_node.py:317-319).  Keep the solution, skip the GPU.
+        sig = self._solved_sig
+        if sig is not None and self._status == 0 and sig[0] == rs.key and sig[1] == max_iter and \
+                sig[2] is self._var_status and np.array_equal(sig[3], l) and np.array_equal(sig[4], u):
+            return self._status
         res = get_backend().solve(rs.A, rs.b, rs.c, l[None], u[None], self._warm_start(rs),
                                   max_iter, rs.key)
         self._store(res, 0)
+        self._solved_sig = (rs.key, max_iter, self._var_status, l, u)
         return self._status
 
     primal = dual  # the engine has one algorithm; results (status/objective/solution) are the same
