@@ -160,6 +160,14 @@ int mipx_tree_solution(mipx_tree *t, double *x);
 int mipx_tree_set_primal_bound(mipx_tree *t, double bound); /* initial_primal_bound / exchange */
 int mipx_tree_pseudo_costs(mipx_tree *t, double *cost_l, double *cost_r, int32_t *times_l,
                            int32_t *times_r);
+/* Copy the records of up to max_nodes open nodes (queue-array order) to HOST buffers without
+ * removing them: l, u (max_nodes x n), vstat (max_nodes x (n+m)), dual_bound (max_nodes); any may
+ * be NULL.  Returns the number copied (used by bench.py to time the CPU oracle on the very LPs the
+ * GPU is about to solve). */
+int64_t mipx_tree_peek_open(mipx_tree *t, int64_t max_nodes, double *l, double *u, int8_t *vstat,
+                            double *dual_bound);
+/* Multi-GPU: keep only this rank's share of the open nodes after a replicated ramp-up. */
+int mipx_tree_keep_shard(mipx_tree *t, int rank, int world);
 /* Test hook: record (node id, LP status, branching variable or -1, objective) per evaluated
  * node; mipx_tree_trace returns the number recorded and copies at most `capacity` of them. */
 int mipx_tree_set_trace(mipx_tree *t, int on);

@@ -23,7 +23,7 @@ SYMBOLS = [
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
     'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
     'mipx_tree_solution', 'mipx_tree_set_primal_bound', 'mipx_tree_pseudo_costs',
-    'mipx_tree_set_trace', 'mipx_tree_trace',
+    'mipx_tree_set_trace', 'mipx_tree_trace', 'mipx_tree_peek_open', 'mipx_tree_keep_shard',
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -99,6 +99,9 @@ def lib():
     L.mipx_tree_set_trace.argtypes = [_vp, C.c_int]
     L.mipx_tree_trace.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, _vp]
     L.mipx_tree_trace.restype = C.c_int64
+    L.mipx_tree_peek_open.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, _vp]
+    L.mipx_tree_peek_open.restype = C.c_int64
+    L.mipx_tree_keep_shard.argtypes = [_vp, C.c_int, C.c_int]
     _lib = L
     return L
 
@@ -285,6 +288,20 @@ class Tree:
                 out[i] = {'left': {'cost': float(cl[i]), 'times': int(tl[i])},
                           'right': {'cost': float(cr[i]), 'times': int(tr[i])}}
         return out
+
+    def peek_open(self, max_nodes):
+        """(l, u, vstat, dual_bound) of up to max_nodes open nodes, without removing them."""
+        n, nv = self.problem.n, self.problem.n + self.problem.m
+        l = np.zeros((max_nodes, n)); u = np.zeros((max_nodes, n))
+        v = np.zeros((max_nodes, nv), np.int8); db = np.zeros(max_nodes)
+        k = lib().mipx_tree_peek_open(self._h, int(max_nodes), _ptr(l), _ptr(u), _ptr(v), _ptr(db))
+        if k < 0:
+            self.problem.ctx.check(int(k), 'mipx_tree_peek_open')
+        return l[:k], u[:k], v[:k], db[:k]
+
+    def keep_shard(self, rank, world):
+        self.problem.ctx.check(lib().mipx_tree_keep_shard(self._h, int(rank), int(world)),
+                               'mipx_tree_keep_shard')
 
     def set_trace(self, on=True):
         self.problem.ctx.check(lib().mipx_tree_set_trace(self._h, int(on)), 'mipx_tree_set_trace')

@@ -29,11 +29,11 @@ struct NodeRec {
 // CPython's heapq on node ids (Lib/heapq.py heappush/heappop/_siftdown/_siftup), so that ties are
 // broken exactly as queue.PriorityQueue breaks them in the reference.
 struct PyHeap {
-    std::vector<int64_t> h;
-    const std::vector<NodeRec> *nodes = nullptr;
-    bool lt(int64_t a, int64_t b) const { return (*nodes)[a].key < (*nodes)[b].key; }
+    struct Item { double key; int64_t id; };
+    std::vector<Item> h;   // keys inline: sifting never touches the node table
+    static bool lt(const Item &a, const Item &b) { return a.key < b.key; }
     void siftdown(size_t startpos, size_t pos) {
-        const int64_t item = h[pos];
+        const Item item = h[pos];
         while (pos > startpos) {
             const size_t parent = (pos - 1) >> 1;
             if (lt(item, h[parent])) { h[pos] = h[parent]; pos = parent; continue; }
@@ -43,7 +43,7 @@ struct PyHeap {
     }
     void siftup(size_t pos) {
         const size_t end = h.size(), start = pos;
-        const int64_t item = h[pos];
+        const Item item = h[pos];
         size_t child = 2 * pos + 1;
         while (child < end) {
             const size_t right = child + 1;
@@ -55,15 +55,15 @@ struct PyHeap {
         h[pos] = item;
         siftdown(start, pos);
     }
-    void push(int64_t id) { h.push_back(id); siftdown(0, h.size() - 1); }
+    void push(double key, int64_t id) { h.push_back({key, id}); siftdown(0, h.size() - 1); }
     int64_t pop() {
-        const int64_t last = h.back();
+        const Item last = h.back();
         h.pop_back();
-        if (h.empty()) return last;
-        const int64_t top = h[0];
+        if (h.empty()) return last.id;
+        const Item top = h[0];
         h[0] = last;
         siftup(0);
-        return top;
+        return top.id;
     }
     bool empty() const { return h.empty(); }
     size_t size() const { return h.size(); }
@@ -82,7 +82,8 @@ struct mipx_tree {
     int32_t *d_int_idx = nullptr, *d_slot = nullptr, *d_status = nullptr, *d_iters = nullptr,
             *d_npiv = nullptr, *d_bidx = nullptr, *d_mipf = nullptr, *d_nprobe = nullptr,
             *d_plist = nullptr, *d_pairs = nullptr;
-    double *d_obj = nullptr, *d_x = nullptr, *d_cost_l = nullptr, *d_cost_r = nullptr;
+    double *d_obj = nullptr, *d_x = nullptr, *d_cost_l = nullptr, *d_cost_r = nullptr,
+           *d_bval = nullptr;
     int8_t *d_vout = nullptr;
     uint8_t *d_has = nullptr;
     // probe pool (strong branching)
@@ -112,6 +113,7 @@ struct mipx_tree {
     std::vector<int32_t> tr_status, tr_bidx;
     std::vector<double> tr_obj;
     bool trace = false;
+    double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // MIPX_TREE_PROFILE=1: host-side breakdown
 };
 
 namespace {
@@ -124,7 +126,7 @@ int dmalloc(mipx_ctx *ctx, T **p, size_t count) {
 
 double tree_open_min(mipx_tree *t) {
     const double inf = std::numeric_limits<double>::infinity();
-    if (t->search == 0) return t->heap.empty() ? inf : t->nodes[t->heap.h[0]].dual_bound;
+    if (t->search == 0) return t->heap.empty() ? inf : t->heap.h[0].key;
     while (!t->open_bounds.empty() && !t->is_open[t->open_bounds.top().second]) t->open_bounds.pop();
     return t->open_bounds.empty() ? inf : t->open_bounds.top().first;
 }
@@ -142,7 +144,7 @@ double tree_gap(mipx_tree *t) {
 }
 
 void tree_push(mipx_tree *t, int64_t id) {
-    t->heap.push(id);
+    t->heap.push(t->nodes[id].key, id);
     if ((size_t)id >= t->is_open.size()) t->is_open.resize(id + 1, 0);
     t->is_open[id] = 1;
     if (t->search != 0) t->open_bounds.push({t->nodes[id].dual_bound, id});
@@ -170,7 +172,8 @@ int launch_score(mipx_tree *t, int batch) {
     s.n = t->n; s.n_int = t->n_int; s.batch = batch; s.rule = t->rule;
     s.int_idx = t->d_int_idx; s.x = t->d_x; s.status = t->d_status;
     s.cost_l = t->d_cost_l; s.cost_r = t->d_cost_r; s.has_entry = t->d_has;
-    s.branch_idx = t->d_bidx; s.mip_feasible = t->d_mipf; s.n_probe = t->d_nprobe;
+    s.branch_idx = t->d_bidx; s.branch_val = t->d_bval; s.mip_feasible = t->d_mipf;
+    s.n_probe = t->d_nprobe;
     s.probe_list = t->d_plist;
     hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, t->ctx->stream, s);
     HIP_TRY(t->ctx, hipGetLastError());
@@ -196,6 +199,11 @@ int tree_step(mipx_tree *t, int want) {
     const int n = t->n, nv = t->n + t->m;
     const double inf = std::numeric_limits<double>::infinity();
     hipStream_t st = ctx->stream;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(now() - t0).count();
+    };
+    auto tp = now();
     // 1. pop the batch (a node whose inherited bound cannot beat the incumbent is closed unevaluated)
     std::vector<int64_t> ids;
     std::vector<int32_t> slots;
@@ -215,6 +223,7 @@ int tree_step(mipx_tree *t, int want) {
     const int B = (int)ids.size();
     if (B == 0) return MIPX_OK;
     t->steps++;
+    t->phase_ms[0] += ms_since(tp); tp = now();
     HIP_TRY(ctx, hipMemcpyAsync(t->d_slot, slots.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     // 2. LP relaxations + scoring
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
@@ -224,7 +233,7 @@ int tree_step(mipx_tree *t, int want) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
     if ((rc = launch_score(t, B))) return rc;
     std::vector<int32_t> status(B), bidx(B), mipf(B), nprobe(B), npiv(B);
-    std::vector<double> obj(B);
+    std::vector<double> obj(B), bval(B);
     HIP_TRY(ctx, hipStreamSynchronize(st));
     {
         float ms = 0.f;
@@ -233,11 +242,13 @@ int tree_step(mipx_tree *t, int want) {
     HIP_TRY(ctx, hipMemcpy(status.data(), t->d_status, (size_t)B * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(obj.data(), t->d_obj, (size_t)B * 8, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(bidx.data(), t->d_bidx, (size_t)B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(bval.data(), t->d_bval, (size_t)B * 8, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(mipf.data(), t->d_mipf, (size_t)B * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(nprobe.data(), t->d_nprobe, (size_t)B * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(npiv.data(), t->d_npiv, (size_t)B * 4, hipMemcpyDeviceToHost));
     t->lps += B;
     for (int k = 0; k < B; k++) t->pivots += npiv[k];
+    t->phase_ms[1] += ms_since(tp); tp = now();
 
     // 3. pseudo costs: strong-branch initialisation + the update for the branch that made the node
     if (t->rule == 1) {
@@ -284,9 +295,11 @@ int tree_step(mipx_tree *t, int want) {
             HIP_TRY(ctx, hipStreamSynchronize(st));
             HIP_TRY(ctx, hipMemcpy(pst.data(), t->pp_status, pst.size() * 4, hipMemcpyDeviceToHost));
             HIP_TRY(ctx, hipMemcpy(pobj.data(), t->pp_obj, pobj.size() * 8, hipMemcpyDeviceToHost));
-            for (int e = 0; e < P; e++)
-                HIP_TRY(ctx, hipMemcpy(&xrow[e], t->d_x + (size_t)pair_pos[e] * n + pair_var[e], 8,
-                                       hipMemcpyDeviceToHost));
+            {   // values of the probed variables: one bulk read of the batch's x
+                std::vector<double> xall((size_t)B * n);
+                HIP_TRY(ctx, hipMemcpy(xall.data(), t->d_x, xall.size() * 8, hipMemcpyDeviceToHost));
+                for (int e = 0; e < P; e++) xrow[e] = xall[(size_t)pair_pos[e] * n + pair_var[e]];
+            }
             t->probes += 2 * P;
         }
         // table updates in the reference's order: node by node; per node its probes (ascending
@@ -324,9 +337,11 @@ int tree_step(mipx_tree *t, int want) {
             if ((rc = launch_score(t, B))) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(st));
             HIP_TRY(ctx, hipMemcpy(bidx.data(), t->d_bidx, (size_t)B * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(bval.data(), t->d_bval, (size_t)B * 8, hipMemcpyDeviceToHost));
         }
     }
 
+    t->phase_ms[2] += ms_since(tp); tp = now();
     // 4. the reference's _evaluate_node bookkeeping, node by node
     std::vector<int32_t> br_pos, br_slot, br_var, br_child;
     int incumbent_pos = -1;
@@ -344,8 +359,7 @@ int tree_step(mipx_tree *t, int want) {
             } else if (bidx[k] >= 0) {
                 if (t->free_slots.size() < 2) return fail(ctx, MIPX_ENOMEM, "tree: node pool exhausted");
                 branched_on = bidx[k];
-                double xv;
-                HIP_TRY(ctx, hipMemcpy(&xv, t->d_x + (size_t)k * n + branched_on, 8, hipMemcpyDeviceToHost));
+                const double xv = bval[k];
                 for (int dir = 0; dir < 2; dir++) {
                     NodeRec c;
                     c.dual_bound = obj[k];
@@ -376,6 +390,7 @@ int tree_step(mipx_tree *t, int want) {
                                hipMemcpyDeviceToHost));
         t->have_x = true;
     }
+    t->phase_ms[3] += ms_since(tp); tp = now();
     // 5. children records on the device, then release the evaluated nodes' rows
     const int P = (int)br_pos.size();
     if (P > 0) {
@@ -399,6 +414,7 @@ int tree_step(mipx_tree *t, int want) {
         t->nodes[ids[k]].slot = -1;
     }
     (void)nv;
+    t->phase_ms[4] += ms_since(tp);
     return MIPX_OK;
 }
 
@@ -427,7 +443,7 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
         if (int_idx[i] < 0 || int_idx[i] >= t->n) { delete t; return fail(ctx, MIPX_EINVAL, "mipx_tree_create: integer index out of range"); }
     const size_t n = t->n, nv = t->n + t->m, cap = (size_t)t->capacity, B = (size_t)max_batch;
     t->probe_cap = 2 * (int64_t)B * (n_int ? n_int : 1);
-    if (t->probe_cap > (int64_t)1 << 22) t->probe_cap = (int64_t)1 << 22;
+    if (t->probe_cap > (int64_t)1 << 18) t->probe_cap = (int64_t)1 << 18;  // 2^18 probe records (~1.2 GB at 256x128)
     const size_t pc = (size_t)t->probe_cap;
     int rc = 0;
     rc |= dmalloc(ctx, &t->pool_l, cap * n); rc |= dmalloc(ctx, &t->pool_u, cap * n);
@@ -439,6 +455,7 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     rc |= dmalloc(ctx, &t->d_plist, B * (size_t)(n_int ? n_int : 1));
     rc |= dmalloc(ctx, &t->d_pairs, 5 * (pc / 2 > B ? pc / 2 : B));
     rc |= dmalloc(ctx, &t->d_obj, B); rc |= dmalloc(ctx, &t->d_x, B * n);
+    rc |= dmalloc(ctx, &t->d_bval, B);
     rc |= dmalloc(ctx, &t->d_vout, B * nv);
     rc |= dmalloc(ctx, &t->d_cost_l, n); rc |= dmalloc(ctx, &t->d_cost_r, n);
     rc |= dmalloc(ctx, &t->d_has, n);
@@ -467,17 +484,20 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     root.depth = 0; root.key = search_rule == 0 ? root.dual_bound : 0.0;
     root.b_idx = -1; root.b_dir = 0; root.b_val = 0.0; root.slot = 0;
     t->nodes.push_back(root);
-    t->heap.nodes = &t->nodes;
     *out = t;
     return MIPX_OK;
 }
 
 void mipx_tree_destroy(mipx_tree *t) {
     if (!t) return;
+    if (std::getenv("MIPX_TREE_PROFILE"))
+        std::fprintf(stderr, "[mipx_tree] steps %lld  pop %.1f ms  lp+score+d2h %.1f ms  pseudo-cost %.1f ms  "
+                     "bookkeeping %.1f ms  children %.1f ms  (lp kernel %.1f ms)\n", (long long)t->steps,
+                     t->phase_ms[0], t->phase_ms[1], t->phase_ms[2], t->phase_ms[3], t->phase_ms[4], t->kernel_ms);
     if (t->ctx) (void)hipSetDevice(t->ctx->device);
     void *ptrs[] = {t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_slot, t->d_status, t->d_iters,
                     t->d_npiv, t->d_bidx, t->d_mipf, t->d_nprobe, t->d_plist, t->d_pairs, t->d_obj,
-                    t->d_x, t->d_vout, t->d_cost_l, t->d_cost_r, t->d_has, t->pp_l, t->pp_u, t->pp_v,
+                    t->d_x, t->d_bval, t->d_vout, t->d_cost_l, t->d_cost_r, t->d_has, t->pp_l, t->pp_u, t->pp_v,
                     t->pp_obj, t->pp_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -570,6 +590,49 @@ int mipx_tree_pseudo_costs(mipx_tree *t, double *cost_l, double *cost_r, int32_t
     std::memcpy(cost_r, t->cost_r.data(), (size_t)t->n * 8);
     std::memcpy(times_l, t->times_l.data(), (size_t)t->n * 4);
     std::memcpy(times_r, t->times_r.data(), (size_t)t->n * 4);
+    return MIPX_OK;
+}
+
+/* Copy the records (bounds + warm-start basis) of up to max_nodes open nodes, in queue-array
+ * order, to host buffers without removing them; returns how many were copied. */
+int64_t mipx_tree_peek_open(mipx_tree *t, int64_t max_nodes, double *l, double *u, int8_t *vstat,
+                            double *dual_bound) {
+    if (!t || max_nodes < 0) return MIPX_EINVAL;
+    mipx_ctx *ctx = t->ctx;
+    const size_t n = t->n, nv = t->n + t->m;
+    int64_t k = 0;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return MIPX_EHIP;
+    for (size_t pos = 0; pos < t->heap.h.size() && k < max_nodes; pos++, k++) {
+        const NodeRec &nd = t->nodes[t->heap.h[pos].id];
+        const size_t s = (size_t)nd.slot;
+        if (l && hipMemcpy(l + k * n, t->pool_l + s * n, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
+        if (u && hipMemcpy(u + k * n, t->pool_u + s * n, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
+        if (vstat && hipMemcpy(vstat + k * nv, t->pool_v + s * nv, nv, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
+        if (dual_bound) dual_bound[k] = nd.dual_bound;
+    }
+    return k;
+}
+
+/* Multi-GPU sharding: after a replicated, deterministic ramp-up every rank
+ * keeps the open nodes whose position in the queue array is congruent to its rank and drops the
+ * others (they live on the other ranks).  The dual bound of the whole tree is then the MIN over
+ * ranks of mipx_tree_stats.dual_bound. */
+int mipx_tree_keep_shard(mipx_tree *t, int rank, int world) {
+    if (!t || world < 1 || rank < 0 || rank >= world) return MIPX_EINVAL;
+    std::vector<PyHeap::Item> old;
+    old.swap(t->heap.h);
+    while (!t->open_bounds.empty()) t->open_bounds.pop();
+    for (size_t pos = 0; pos < old.size(); pos++) {
+        const int64_t id = old[pos].id;
+        t->is_open[id] = 0;
+        if ((int)(pos % (size_t)world) == rank) {
+            tree_push(t, id);
+        } else {
+            t->free_slots.push_back(t->nodes[id].slot);
+            t->nodes[id].slot = -1;
+        }
+    }
+    if (rank != 0) t->closed_min = std::numeric_limits<double>::infinity();  // counted once, on rank 0
     return MIPX_OK;
 }
 

@@ -23,6 +23,7 @@ struct ScoreArgs {
     const double *cost_l, *cost_r;  // n (pseudo-cost table by variable)
     const uint8_t *has_entry;       // n
     int32_t *branch_idx;            // batch: variable to branch on or -1
+    double *branch_val;             // batch: x[branch_idx] (b_val of the children)
     int32_t *mip_feasible;          // batch
     int32_t *n_probe;               // batch
     int32_t *probe_list;            // batch x n_int (ascending position in int_idx)
@@ -74,7 +75,9 @@ __global__ __launch_bounds__(64) void branch_score(ScoreArgs g) {
     const int win = wave_argmax(bk, bp, km);
     if (lane == 0) {
         g.mip_feasible[node] = wmax <= kVarEps;
-        g.branch_idx[node] = win == kNoCand ? -1 : g.int_idx[win];
+        const int bvar = win == kNoCand ? -1 : g.int_idx[win];
+        g.branch_idx[node] = bvar;
+        g.branch_val[node] = bvar < 0 ? 0.0 : x[bvar];
         g.n_probe[node] = nprobe;
     }
 }

@@ -1,0 +1,56 @@
+"""The N > 1 exchange path on CPU: two processes, gloo backend (no GPU needed)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from simple_mip_solver_amd.parallel import exchange, global_gap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INF = float('inf')
+
+
+def test_single_process_passthrough():
+    assert exchange(None, 'cpu', -3.0, -5.0, [1, 2]) == (-3.0, -5.0, [1, 2], 0)
+    assert global_gap(-2, -2.25) == .125 and global_gap(INF, -3) is None and global_gap(0, 0) == 0
+
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import torch.distributed as dist
+    from simple_mip_solver_amd.parallel import exchange
+    dist.init_process_group('gloo')
+    rank = dist.get_rank()
+    INF = float('inf')
+    # step 1: nobody has an incumbent; rank 1's shard has the weaker dual bound
+    out = exchange(dist, 'cpu', INF, [-10.0, -12.5][rank], [3 + rank, 100 * (rank + 1)])
+    assert out == (INF, -12.5, [7, 300], 2), out
+    # step 2: rank 1 finds an incumbent, rank 0 has run out of open nodes
+    out = exchange(dist, 'cpu', [INF, -9.0][rank], [INF, -9.5][rank], [1, 1])
+    assert out == (-9.0, -9.5, [2, 2], 1), out
+    # step 3: both hold the same incumbent value: the lowest rank is reported
+    out = exchange(dist, 'cpu', -9.0, -9.0, [0, 0])
+    assert out == (-9.0, -9.0, [0, 0], 0), out
+    dist.barrier()
+    dist.destroy_process_group()
+    print('rank', rank, 'ok')
+''')
+
+
+def test_two_rank_exchange_over_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                          '--nproc-per-node=2', '--master-addr', '127.0.0.1', '--master-port',
+                          str(port), str(script)], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert 'rank 0 ok' in res.stdout and 'rank 1 ok' in res.stdout
