@@ -95,6 +95,16 @@ int mipx_lp_solve_batch_dev(mipx_problem *p, int batch, const double *l, const d
                             double *x, double *y, int8_t *vstat_out, int32_t *iters,
                             int32_t *npivots);
 
+/*
+ * Independent problems, one per LP (BASELINE config C2: a batch of root relaxations of different
+ * random instances): A is batch x m x n, b batch x m, c batch x n, l/u batch x n; cold start.
+ * Replaces a Python loop of `BaseNode(model_k.lp, ...).bound()` over models (base_node.py:259-286).
+ */
+int mipx_lp_solve_multi(mipx_ctx *ctx, int m, int n, int batch, const double *A, const double *b,
+                        const double *c, const double *l, const double *u, int max_iter,
+                        int32_t *status, double *obj, double *x, int8_t *vstat_out, int32_t *iters,
+                        int32_t *npivots);
+
 /* Device memory owned by the library, for the device-resident entry points. */
 int mipx_dev_alloc(mipx_ctx *ctx, size_t bytes, void **dptr);
 int mipx_dev_free(mipx_ctx *ctx, void *dptr);

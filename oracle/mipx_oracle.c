@@ -36,6 +36,8 @@
  *      two-component numbers a + b*M; beta = beta0 - T v_N with a fold-in-half summation tree.
  *   3. dual simplex: leaving row = largest bound violation (M-level beats real level, ties ->
  *      lowest variable index); Harris two-pass ratio test (ties -> lowest variable index);
+ *      after more than m+n consecutive degenerate steps (entering d_j <= DTOL) Bland's rule takes
+ *      over until a non-degenerate step (anti-cycling);
  *      rank-1 tableau update with explicit fma; the pivot row is scaled by the reciprocal
  *      1/p (one division per pivot), as the kernel does.
  *   4. status 0 optimal / 1 primal infeasible / 2 unbounded (optimum depends on M) /
@@ -214,8 +216,10 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
 
     /* 3. dual simplex */
     int iters = 0, status = -1;
+    int degen = 0; /* consecutive degenerate steps; > m+n switches to Bland's rule (anti-cycling) */
     const int cap = 100 * (m + n) + 1000;
     for (;;) {
+        const int bland = degen > m + n;
         /* (a) leaving row */
         int r = -1, rlevel = 0, rvar = 0, sigma = 0; double rviol = 0.0;
         for (int i = 0; i < m; i++) {
@@ -233,6 +237,7 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
                 else if (!isinf(up) && a > up + MIPX_PTOL) { level = 1; viol = a - up; sg = -1; }
             }
             if (level == 0) continue;
+            if (bland) { level = 1; viol = 0.0; } /* Bland: lowest variable index among violated */
             int better = 0;
             if (r < 0) better = 1;
             else if (level != rlevel) better = level > rlevel;
@@ -257,7 +262,7 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
             int elig = nb_up[j] == 0 ? (a < -MIPX_PIVTOL) : (a > MIPX_PIVTOL);
             if (!elig) continue;
             double dj = nb_up[j] == 0 ? fmax(t.d[j], 0.0) : fmax(-t.d[j], 0.0);
-            double ratio = (dj + MIPX_DTOL) / fabs(a);
+            double ratio = bland ? dj / fabs(a) : (dj + MIPX_DTOL) / fabs(a);
             if (jmin < 0 || ratio < thmax || (ratio == thmax && v < jminvar)) {
                 thmax = ratio; jmin = j; jminvar = v;
             }
@@ -266,7 +271,7 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
         /* pass 2: largest |a| among columns with dj <= thmax*|a| (the pass-1 argmin always
          * qualifies); ties -> lowest variable index */
         int q = -1, qvar = 0; double qabs = 0.0;
-        for (int j = 0; j < n; j++) {
+        for (int j = 0; j < n && !bland; j++) {
             int v = t.nvar[j];
             if (VLO(v) == VUP(v)) continue;
             double a = sigma * Tr[j];
@@ -276,6 +281,11 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
             double aa = fabs(a);
             if (j != jmin && dj > thmax * aa) continue;
             if (q < 0 || aa > qabs || (aa == qabs && v < qvar)) { q = j; qabs = aa; qvar = v; }
+        }
+        if (bland) q = jmin; /* textbook ratio test, ties -> lowest variable index */
+        {
+            const double djq = nb_up[q] == 0 ? fmax(t.d[q], 0.0) : fmax(-t.d[q], 0.0);
+            degen = djq <= MIPX_DTOL ? degen + 1 : 0;
         }
         /* (c) value update + pivot */
         {

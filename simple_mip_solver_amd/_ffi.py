@@ -18,7 +18,7 @@ ERRORS = {-1: 'MIPX_EINVAL', -2: 'MIPX_ENODEV', -3: 'MIPX_EHIP', -4: 'MIPX_ETOOB
 SYMBOLS = [
     'mipx_abi_version', 'mipx_device_count', 'mipx_ctx_create', 'mipx_ctx_destroy',
     'mipx_last_error', 'mipx_ctx_sync', 'mipx_problem_create', 'mipx_problem_destroy',
-    'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_dev_alloc', 'mipx_dev_free',
+    'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_lp_solve_multi', 'mipx_dev_alloc', 'mipx_dev_free',
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
     'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
@@ -79,6 +79,7 @@ def lib():
     solve_args = [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     L.mipx_lp_solve_batch.argtypes = solve_args
     L.mipx_lp_solve_batch_dev.argtypes = solve_args
+    L.mipx_lp_solve_multi.argtypes = [_vp, C.c_int, C.c_int, C.c_int] + [_vp] * 5 + [C.c_int] + [_vp] * 6
     L.mipx_dev_alloc.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
     L.mipx_dev_free.argtypes = [_vp, _vp]
     L.mipx_memcpy_h2d.argtypes = [_vp, _vp, _vp, C.c_size_t]
@@ -174,6 +175,23 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def solve_multi(ctx, A, b, c, l, u, max_iter=0):
+    """Root relaxations of `batch` independent problems of one shape (cold start)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    B, m, n = A.shape
+    b = np.ascontiguousarray(b, dtype=np.float64).reshape(B, m)
+    c = np.ascontiguousarray(c, dtype=np.float64).reshape(B, n)
+    l = np.ascontiguousarray(l, dtype=np.float64).reshape(B, n)
+    u = np.ascontiguousarray(u, dtype=np.float64).reshape(B, n)
+    status = np.zeros(B, np.int32); obj = np.zeros(B); x = np.zeros((B, n))
+    vout = np.zeros((B, n + m), np.int8); iters = np.zeros(B, np.int32); npiv = np.zeros(B, np.int32)
+    rc = lib().mipx_lp_solve_multi(ctx._h, m, n, B, _ptr(A), _ptr(b), _ptr(c), _ptr(l), _ptr(u),
+                                   int(max_iter), _ptr(status), _ptr(obj), _ptr(x), _ptr(vout),
+                                   _ptr(iters), _ptr(npiv))
+    ctx.check(rc, 'mipx_lp_solve_multi')
+    return dict(status=status, obj=obj, x=x, vstat=vout, iters=iters, npivots=npiv)
 
 
 class Problem:

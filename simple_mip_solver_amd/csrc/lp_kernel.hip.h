@@ -33,7 +33,8 @@ constexpr double kMReport = 1e10;  // stands for the symbolic bound M when repor
 
 struct LpArgs {
     int m, n;
-    const double *A, *b, *c;       // shared by the batch
+    const double *A, *b, *c;       // shared by the batch (strides 0) or one problem per node
+    size_t A_stride, b_stride, c_stride;  // elements between consecutive nodes' A / b / c
     const double *l, *u;           // batch x n
     const int8_t *vstat_in;        // batch x (n+m) or nullptr
     const int32_t *slot;           // optional: node k reads l/u/vstat_in at row slot[k] (node pool)
@@ -160,6 +161,9 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
     {
         double T[R][C];
         const size_t src = g.slot ? (size_t)g.slot[node] : (size_t)node;
+        const double *gA = g.A + (size_t)node * g.A_stride;
+        const double *gb = g.b + (size_t)node * g.b_stride;
+        const double *gc = g.c + (size_t)node * g.c_stride;
         const double *lk = g.l + src * n;
         const double *uk = g.u + src * n;
         const int8_t *vin = g.vstat_in ? g.vstat_in + src * nv : nullptr;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
 #pragma unroll
         for (int ii = 0; ii < R; ii++) {
             const int i = bi + TBI * ii;
-            const double *arow = g.A + (size_t)(i < m ? i : 0) * n + bj;  // one base per row
+            const double *arow = gA + (size_t)(i < m ? i : 0) * n + bj;  // one base per row
 #pragma unroll
             for (int jj = 0; jj < C; jj++) {
                 const int j = bj + TBJ * jj;
@@ -177,14 +181,14 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
         }
 #pragma unroll 1
         for (int i = tid; i < MP; i += NT) {
-            s.beta0[i] = i < m ? -g.b[i] : 0.0;
+            s.beta0[i] = i < m ? -gb[i] : 0.0;
             s.bvar[i] = i < m ? n + i : -1;
             s.ba[i] = 0.0;
             s.bb[i] = 0.0;
         }
 #pragma unroll 1
         for (int j = tid; j < NP; j += NT) {
-            s.d[j] = j < n ? g.c[j] : 0.0;
+            s.d[j] = j < n ? gc[j] : 0.0;
             s.nvar[j] = j < n ? j : -1;
             s.lo[j] = j < n ? lk[j] : 0.0;
             s.up[j] = j < n ? uk[j] : 0.0;
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
         // instruction stream).  All waves take part in the tableau update.
         constexpr int CT = NT < 256 ? NT : 256;
         const bool ctl = tid < CT;
+        int degen = 0;  // consecutive degenerate steps (control waves); > m+n -> Bland's rule
 
         for (;;) {
             int r = 0, q = 0, sigma = 1, newside = 0;
@@ -343,6 +348,7 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
             } else {
                 // ---- 3. dual simplex iteration ----------------------------------------------
                 // (a) leaving row, by the control waves
+                const bool bland = degen > m + n;
                 if (ctl) {
                     int blevel = 0, bp = kNoCand;
                     double bk = -INF;
@@ -364,6 +370,7 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                                 if (a < lo - kPTol) { level = 1; viol = lo - a; sg = 1; }
                                 else if (!isinf(up) && a > up + kPTol) { level = 1; viol = a - up; sg = -1; }
                             }
+                            if (bland && level > 0) { level = 1; viol = 0.0; }  // lowest variable wins
                             // payload: variable index (tie-break), direction flag, row
                             const int pay = (v << 16) | (sg < 0 ? 0x8000 : 0) | i;
                             const bool up_lvl = level > blevel;
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                         const bool elig = lo != up && (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
                         const double dj = sd == 0 ? fmax(s.d[j], 0.0) : fmax(-s.d[j], 0.0);
                         const double aa = fabs(a);
-                        s.key[j] = elig ? (dj + kDTol) / aa : INF;
+                        s.key[j] = elig ? (bland ? dj / aa : (dj + kDTol) / aa) : INF;
                         s.aabs[j] = elig ? aa : -1.0;
                         s.dje[j] = dj;
                     }
@@ -435,7 +442,9 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                     double nthmax;
                     const int w1 = wave_argmax(k1, p1, nthmax);
                     int qq = -1;
-                    if (w1 != kNoCand) {
+                    if (w1 != kNoCand && bland) {
+                        qq = w1 & 0xffff;  // textbook ratio test, ties -> lowest variable index
+                    } else if (w1 != kNoCand) {
                         const double thmax = -nthmax;
                         const int jmin = w1 & 0xffff;
                         double k2 = -INF;
@@ -452,6 +461,7 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                         double amax;
                         qq = wave_argmax(k2, p2, amax) & 0xffff;
                     }
+                    if (qq >= 0) degen = s.dje[qq] <= kDTol ? degen + 1 : 0;
                     if (tid == 0) {
                         s.ci[0] = qq;
                         if (qq >= 0) s.cd[0] = 1.0 / s.row[qq];
@@ -607,7 +617,7 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
 #pragma unroll
             for (int k = 0; k < PER; k++) {
                 const int j = lane + 64 * k;
-                p[k] = j < n ? g.c[j] * s.key[j] : 0.0;
+                p[k] = j < n ? gc[j] * s.key[j] : 0.0;
             }
 #pragma unroll
             for (int h = PER / 2; h >= 1; h >>= 1) {

@@ -185,6 +185,7 @@ int mipx_lp_solve_batch_dev(mipx_problem *p, int batch, const double *l, const d
     mipx::LpArgs a;
     a.m = p->m; a.n = p->n;
     a.A = p->dA; a.b = p->db; a.c = p->dc;
+    a.A_stride = a.b_stride = a.c_stride = 0;
     a.l = l; a.u = u; a.vstat_in = vstat_in; a.slot = nullptr; a.max_iter = max_iter;
     a.status = status; a.obj = obj; a.x = x; a.y = y; a.vstat_out = vstat_out;
     a.iters = iters; a.npivots = npivots; a.batch = batch;
@@ -261,6 +262,59 @@ int mipx_debug_read(mipx_problem *p, double *T, double *vec, int32_t *idx) {
     if (vec) HIP_TRY(ctx, hipMemcpy(vec, p->dbg_vec, (n + 3 * m) * 8, hipMemcpyDeviceToHost));
     if (idx) HIP_TRY(ctx, hipMemcpy(idx, p->dbg_idx, (2 * n + m) * 4, hipMemcpyDeviceToHost));
     return MIPX_OK;
+}
+
+int mipx_lp_solve_multi(mipx_ctx *ctx, int m, int n, int batch, const double *A, const double *b,
+                        const double *c, const double *l, const double *u, int max_iter,
+                        int32_t *status, double *obj, double *x, int8_t *vstat_out, int32_t *iters,
+                        int32_t *npivots) {
+    if (!ctx || batch < 0 || m < 0 || n <= 0 || (batch && (!A || !b || !c || !l || !u)))
+        return fail(ctx, MIPX_EINVAL, "mipx_lp_solve_multi: bad argument");
+    if (batch == 0) return MIPX_OK;
+    const KernelCfg *cfg = pick_cfg(m, n);
+    if (!cfg) return fail(ctx, MIPX_ETOOBIG, "mipx_lp_solve_multi: (m,n) too big");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t B = (size_t)batch, nn = (size_t)n, mm = (size_t)(m ? m : 1), nv = (size_t)n + m;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_A = carve(B * mm * nn * 8), o_b = carve(B * mm * 8), o_c = carve(B * nn * 8),
+                 o_l = carve(B * nn * 8), o_u = carve(B * nn * 8), o_st = carve(B * 4),
+                 o_obj = carve(B * 8), o_x = carve(B * nn * 8), o_v = carve(B * nv),
+                 o_it = carve(B * 4), o_np = carve(B * 4);
+    char *base = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&base, off));
+    hipStream_t st = ctx->stream;
+    int rc = MIPX_OK;
+    auto up = [&](size_t o, const void *src, size_t bytes) {
+        if (rc == MIPX_OK && hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+            rc = fail(ctx, MIPX_EHIP, "mipx_lp_solve_multi: upload");
+    };
+    up(o_A, A, B * (size_t)m * nn * 8); up(o_b, b, B * (size_t)m * 8); up(o_c, c, B * nn * 8);
+    up(o_l, l, B * nn * 8); up(o_u, u, B * nn * 8);
+    if (rc == MIPX_OK) {
+        mipx::LpArgs a;
+        a.m = m; a.n = n;
+        a.A = (const double *)(base + o_A); a.b = (const double *)(base + o_b);
+        a.c = (const double *)(base + o_c);
+        a.A_stride = (size_t)m * nn; a.b_stride = (size_t)m; a.c_stride = nn;
+        a.l = (const double *)(base + o_l); a.u = (const double *)(base + o_u);
+        a.vstat_in = nullptr; a.slot = nullptr; a.max_iter = max_iter;
+        a.status = (int32_t *)(base + o_st); a.obj = (double *)(base + o_obj);
+        a.x = (double *)(base + o_x); a.y = nullptr; a.vstat_out = (int8_t *)(base + o_v);
+        a.iters = (int32_t *)(base + o_it); a.npivots = (int32_t *)(base + o_np); a.batch = batch;
+        a.dbg_T = nullptr; a.dbg_vec = nullptr; a.dbg_idx = nullptr;
+        cfg->launch(a, batch, st);
+        if (hipGetLastError() != hipSuccess) rc = fail(ctx, MIPX_EHIP, "mipx_lp_solve_multi: launch");
+    }
+    auto down = [&](void *dst, size_t o, size_t bytes) {
+        if (dst && rc == MIPX_OK && hipMemcpyAsync(dst, base + o, bytes, hipMemcpyDeviceToHost, st) != hipSuccess)
+            rc = fail(ctx, MIPX_EHIP, "mipx_lp_solve_multi: download");
+    };
+    down(status, o_st, B * 4); down(obj, o_obj, B * 8); down(x, o_x, B * nn * 8);
+    down(vstat_out, o_v, B * nv); down(iters, o_it, B * 4); down(npivots, o_np, B * 4);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == MIPX_OK) rc = fail(ctx, MIPX_EHIP, "mipx_lp_solve_multi: sync");
+    (void)hipFree(base);
+    return rc;
 }
 
 int mipx_dev_alloc(mipx_ctx *ctx, size_t bytes, void **dptr) {

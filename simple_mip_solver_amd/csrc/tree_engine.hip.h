@@ -158,6 +158,7 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
     mipx::LpArgs a;
     a.m = t->m; a.n = t->n;
     a.A = t->prob->dA; a.b = t->prob->db; a.c = t->prob->dc;
+    a.A_stride = a.b_stride = a.c_stride = 0;
     a.l = l; a.u = u; a.vstat_in = v; a.slot = slot; a.max_iter = max_iter;
     a.status = status; a.obj = obj; a.x = x; a.y = nullptr; a.vstat_out = vout;
     a.iters = iters; a.npivots = npiv; a.batch = batch;

@@ -149,3 +149,23 @@ def test_warm_start_with_padding_after_lds_pollution(gpu_ctx, oracle):
         L, U, V = _children(A, b, c, l, u, root, 6)
         if len(L):
             assert_same(p.solve_batch(L, U, V), oracle.lp_solve_batch(A, b, c, L, U, V), f'{n}x{m}')
+
+
+def test_c2_batch_of_1024_independent_roots(gpu_ctx, oracle):
+    """BASELINE config C2: 1024 random dense MILPs, 64 vars x 32 rows, seeds 0..1023, root
+    relaxation of each (cold start), one launch."""
+    probs = [random_dense_milp_arrays(64, 32, seed=s) for s in range(1024)]
+    A = np.stack([p[0] for p in probs]); b = np.stack([p[1] for p in probs])
+    c = np.stack([p[2] for p in probs]); l = np.stack([p[3] for p in probs])
+    u = np.stack([p[4] for p in probs])
+    g = _ffi.solve_multi(gpu_ctx, A, b, c, l, u)
+    assert np.all(g['status'] == 0)
+    for k in range(0, 1024, 8):  # the oracle on every 8th instance: bit-exact
+        o = oracle.lp_solve_batch(A[k], b[k], c[k], l[k][None], u[k][None])
+        for key in ('status', 'iters', 'npivots', 'vstat', 'x', 'obj'):
+            assert np.array_equal(g[key][k:k + 1], o[key]), (k, key)
+    # every instance: feasibility and the size-independent LP bound property
+    for k in range(1024):
+        assert np.all(A[k] @ g['x'][k] >= b[k] - 1e-6)
+        assert np.all(g['x'][k] >= -1e-9) and np.all(g['x'][k] <= 10 + 1e-9)
+        assert abs(g['obj'][k] - c[k] @ g['x'][k]) <= 1e-9 * max(1, abs(g['obj'][k]))
