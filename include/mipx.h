@@ -105,6 +105,26 @@ int mipx_lp_solve_multi(mipx_ctx *ctx, int m, int n, int batch, const double *A,
                         int32_t *status, double *obj, double *x, int8_t *vstat_out, int32_t *iters,
                         int32_t *npivots);
 
+/*
+ * Batched Gomory mixed-integer cuts with numerically safe rounding: replaces
+ * BaseNode.tableau + _find_gomory_cuts (base_node.py:468-530) and the numerically_safe_cut call of
+ * _generate_cuts (base_node.py:381, utils/floating_point.py:40-167) for `batch` solved nodes.
+ *   l, u, vstat   the nodes' bounds and OPTIMAL basis (getBasisStatus after the solve)
+ *   x             batch x n  the nodes' solutions clipped at 0 (base_node.py:310)
+ *   is_int        n bytes, 1 for integer variables
+ *   max_term      utils/tolerance.py max_term (1e3)
+ *   ncuts         batch        number of cuts generated per node
+ *   row_idx       batch x m    tableau row of each cut = rank of its basic variable (the suffix
+ *                              of the reference's cut name cut_gomory_<node>_<round>_<row>)
+ *   pi, pi0       batch x m x n, batch x m   raw cuts  pi.x >= pi0
+ *   safe_pi(0)    same shapes: the rounded outer approximation ('over' estimate)
+ * All pointers are HOST pointers; outputs other than ncuts may be NULL.
+ */
+int mipx_gomory_batch(mipx_problem *p, int batch, const double *l, const double *u,
+                      const int8_t *vstat, const double *x, const uint8_t *is_int, double max_term,
+                      int32_t *ncuts, int32_t *row_idx, double *pi, double *pi0, double *safe_pi,
+                      double *safe_pi0);
+
 /* Device memory owned by the library, for the device-resident entry points. */
 int mipx_dev_alloc(mipx_ctx *ctx, size_t bytes, void **dptr);
 int mipx_dev_free(mipx_ctx *ctx, void *dptr);

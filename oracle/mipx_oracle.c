@@ -440,3 +440,156 @@ void mipx_oracle_pseudo_cost_update(double *cost, int32_t *times, int status, do
     }
     *times += 1;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Cut rounding: utils/floating_point.py (get_fraction :106-167, scale_cut :11-37,
+ * numerically_safe_cut :40-103 with make_integer=False, the form used at base_node.py:381).
+ * Numerators / denominators are carried as doubles holding integers (exact below 2^53; anything
+ * larger has already exceeded max_term and only ends the expansion).
+ * ---------------------------------------------------------------------------------------- */
+#define EST_NONE 0
+#define EST_OVER 1
+#define EST_UNDER 2
+
+void mipx_oracle_get_fraction(double x, double max_term, int estimate, double *n_out, double *d_out) {
+    if (fabs(x) > max_term) {
+        *n_out = estimate == EST_OVER ? ceil(x) : estimate == EST_UNDER ? floor(x) : rint(x);
+        *d_out = 1.0;
+        return;
+    }
+    /* convergents h_k / k_k; index 0,1 hold h_{-2}, h_{-1} */
+    double hn[72], hd[72];
+    hn[0] = 0.0; hd[0] = 1.0; hn[1] = 1.0; hd[1] = 0.0;
+    int cnt = 2, exact = 0;
+    double value = x;
+    for (;;) {
+        const double whole = floor(value);
+        hn[cnt] = whole * hn[cnt - 1] + hn[cnt - 2];
+        hd[cnt] = whole * hd[cnt - 1] + hd[cnt - 2];
+        cnt++;
+        if (hn[cnt - 1] > max_term || hd[cnt - 1] > max_term || cnt >= 70) break;
+        const double rem = value - whole;
+        if (rem == 0.0) { exact = 1; break; }
+        value = 1.0 / rem;
+    }
+    const int last = cnt - 3; /* index (0-based, convergent numbering) of the final convergent */
+    int pick;
+    if (exact) pick = last;
+    else {
+        const int prev = last - 1;
+        if (estimate == EST_NONE) pick = prev;
+        else if (estimate == EST_OVER) {
+            /* Python: (i-1) % 2 truthy -> prev (also for prev = -1), else prev-1 if >= 0 else ceil */
+            if (prev % 2 != 0) pick = prev;
+            else if (prev >= 1) pick = prev - 1;
+            else { *n_out = ceil(x); *d_out = 1.0; return; }
+        } else {
+            pick = (prev % 2 == 0) ? prev : prev - 1;
+        }
+    }
+    *n_out = hn[pick + 2];
+    *d_out = hd[pick + 2];
+}
+
+/* pi (n coefficients), pi0 -> safe_pi, safe_pi0; estimate EST_OVER / EST_UNDER.
+ * Returns 0 if pi is all zero (cut returned unchanged), 1 otherwise. */
+int mipx_oracle_safe_cut(int n, const double *pi, double pi0, int estimate, double max_term,
+                         double *safe_pi, double *safe_pi0) {
+    double scale = INFINITY;
+    int any = 0;
+    for (int j = 0; j < n; j++) {
+        if (pi[j] != 0.0) any = 1;
+        const double s = fabs(1.0 / pi[j]);
+        if (s < scale) scale = s;
+    }
+    if (!any) {
+        for (int j = 0; j < n; j++) safe_pi[j] = pi[j];
+        *safe_pi0 = pi0;
+        return 0;
+    }
+    for (int j = 0; j < n; j++) {
+        const double coef = pi[j] * scale;
+        double nn, dd;
+        mipx_oracle_get_fraction(coef, max_term, estimate, &nn, &dd);
+        if (coef != 0.0 && fabs(1.0 - ((nn / dd) / coef)) > 1e-2) {
+            double n2, d2;
+            mipx_oracle_get_fraction(coef, max_term, EST_NONE, &n2, &d2);
+            if (fabs(n2 / d2 - coef) < 1e-14) { nn = n2; dd = d2; }
+        }
+        safe_pi[j] = nn / dd;
+    }
+    double n0, d0;
+    mipx_oracle_get_fraction(pi0 * scale, 1e3 /* the reference passes no max_term here */,
+                             estimate == EST_OVER ? EST_UNDER : EST_OVER, &n0, &d0);
+    *safe_pi0 = n0 / d0;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Gomory mixed-integer cuts from the condensed tableau (base_node.py:468-511): for every row whose
+ * basic variable is an integer structural with fractional value (f0 in [0.01, 0.99]), in the
+ * order of ascending basic variable index (= row order of inv(A_B) [A | -I] in the reference),
+ *   integer nonbasic j:    f = a - floor(a);  f <= f0 ? f/f0 : (1-f)/(1-f0)
+ *   continuous / slack:    a > 0 ? a/f0 : -a/(1-f0)
+ * then the slacks s = Ax - b are substituted out: coefs = pi + A' pi_s (accumulated row by row),
+ * rhs = 1 + pi_s . b (fold-in-half tree), and the cut is rounded by mipx_oracle_safe_cut('over').
+ * T is the m x n condensed tableau of the basis, bvar/nvar its row/column variables.
+ * Returns the number of cuts; row_idx[k] is the rank of the generating basic variable.
+ * ---------------------------------------------------------------------------------------- */
+int mipx_oracle_gomory(int m, int n, const double *A, const double *b, const double *T,
+                       const int32_t *bvar, const int32_t *nvar, const double *x,
+                       const uint8_t *is_int, double max_term, int32_t *row_idx, double *pi,
+                       double *pi0, double *safe_pi, double *safe_pi0) {
+    int *order = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    for (int i = 0; i < m; i++) {
+        int rank = 0;
+        for (int k = 0; k < m; k++) rank += bvar[k] < bvar[i];
+        order[rank] = i;
+    }
+    double *pv = (double *)malloc(sizeof(double) * (size_t)n);
+    double *ps = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    int m2 = 1;
+    while (m2 < m) m2 <<= 1;
+    double *buf = (double *)malloc(sizeof(double) * (size_t)m2);
+    int ncuts = 0;
+    for (int rank = 0; rank < m; rank++) {
+        const int r = order[rank], v = bvar[r];
+        if (v >= n || !is_int[v]) continue;
+        const double xv = x[v], fl = floor(xv), ce = ceil(xv);
+        if (!(fmin(xv - fl, ce - xv) > VARIABLE_EPSILON)) continue;
+        const double f0 = xv - fl;
+        if (f0 < 1e-2 || f0 + 1e-2 > 1.0) continue;
+        for (int j = 0; j < n; j++) pv[j] = 0.0;
+        for (int i = 0; i < m; i++) ps[i] = 0.0;
+        for (int j = 0; j < n; j++) {
+            const int var = nvar[j];
+            const double a = T[(size_t)r * n + j];
+            const double cont = a > 0.0 ? a / f0 : -a / (1.0 - f0);
+            if (var < n) {
+                double val = cont;
+                if (is_int[var]) {
+                    const double f = a - floor(a);
+                    val = f <= f0 ? f / f0 : (1.0 - f) / (1.0 - f0);
+                }
+                pv[var] = val;
+            } else {
+                ps[var - n] = cont;
+            }
+        }
+        double *out = pi + (size_t)ncuts * n;
+        for (int var = 0; var < n; var++) {
+            double acc = 0.0;
+            for (int i = 0; i < m; i++) acc = acc + A[(size_t)i * n + var] * ps[i];
+            out[var] = pv[var] + acc;
+        }
+        for (int i = 0; i < m; i++) buf[i] = ps[i] * b[i];
+        for (int i = m; i < m2; i++) buf[i] = 0.0;
+        pi0[ncuts] = 1.0 + fold_sum(buf, m2);
+        row_idx[ncuts] = rank;
+        mipx_oracle_safe_cut(n, out, pi0[ncuts], EST_OVER, max_term, safe_pi + (size_t)ncuts * n,
+                             safe_pi0 + ncuts);
+        ncuts++;
+    }
+    free(order); free(pv); free(ps); free(buf);
+    return ncuts;
+}

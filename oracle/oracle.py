@@ -121,3 +121,46 @@ def debug_dump(A, b, c, l, u, vstat=None, max_iter=0):
         lib().mipx_oracle_set_dump(None, None, None)
     return res, dict(T=T, d=vec[:n], beta0=vec[n:n + m], ba=vec[n + m:n + 2 * m],
                      bb=vec[n + 2 * m:], nvar=idx[:n], bvar=idx[n:n + m], side=idx[n + m:])
+
+
+_EST = {None: 0, 'over': 1, 'under': 2}
+
+
+def get_fraction(x, max_term=1e3, estimate=None):
+    n = C.c_double(); d = C.c_double()
+    lib().mipx_oracle_get_fraction(C.c_double(x), C.c_double(max_term), C.c_int(_EST[estimate]),
+                                   C.byref(n), C.byref(d))
+    return int(n.value), int(d.value)
+
+
+def safe_cut(pi, pi0, estimate='over', max_term=1e3):
+    pi = np.ascontiguousarray(pi, np.float64)
+    out = np.zeros_like(pi); out0 = C.c_double()
+    lib().mipx_oracle_safe_cut(C.c_int(len(pi)), _p(pi, _dp), C.c_double(pi0),
+                               C.c_int(_EST[estimate]), C.c_double(max_term), _p(out, _dp),
+                               C.byref(out0))
+    return out, out0.value
+
+
+def gomory(A, b, c, l, u, vstat, x, int_idx, max_term=1e3):
+    """GMI cuts (+ safe rounding) for the basis `vstat` of one node LP; x is the node's solution.
+
+    Returns dict(row_idx, pi, pi0, safe_pi, safe_pi0) with one row per cut.
+    """
+    A = np.ascontiguousarray(A, np.float64)
+    m, n = A.shape
+    b = np.ascontiguousarray(b, np.float64)
+    _, dump = debug_dump(A, b, c, l, u, vstat, 0)
+    T = np.ascontiguousarray(dump['T']); bvar = np.ascontiguousarray(dump['bvar'], np.int32)
+    nvar = np.ascontiguousarray(dump['nvar'], np.int32)
+    is_int = np.zeros(n, np.uint8); is_int[np.asarray(int_idx, int)] = 1
+    xs = np.ascontiguousarray(np.maximum(np.asarray(x, np.float64), 0))
+    row_idx = np.zeros(m, np.int32); pi = np.zeros((m, n)); pi0 = np.zeros(m)
+    spi = np.zeros((m, n)); spi0 = np.zeros(m)
+    lib().mipx_oracle_gomory.restype = C.c_int
+    k = lib().mipx_oracle_gomory(C.c_int(m), C.c_int(n), _p(A, _dp), _p(b, _dp), _p(T, _dp),
+                                 _p(bvar, _i32p), _p(nvar, _i32p), _p(xs, _dp),
+                                 is_int.ctypes.data_as(C.c_void_p), C.c_double(max_term),
+                                 _p(row_idx, _i32p), _p(pi, _dp), _p(pi0, _dp), _p(spi, _dp),
+                                 _p(spi0, _dp))
+    return dict(row_idx=row_idx[:k], pi=pi[:k], pi0=pi0[:k], safe_pi=spi[:k], safe_pi0=spi0[:k])

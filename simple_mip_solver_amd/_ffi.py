@@ -18,7 +18,7 @@ ERRORS = {-1: 'MIPX_EINVAL', -2: 'MIPX_ENODEV', -3: 'MIPX_EHIP', -4: 'MIPX_ETOOB
 SYMBOLS = [
     'mipx_abi_version', 'mipx_device_count', 'mipx_ctx_create', 'mipx_ctx_destroy',
     'mipx_last_error', 'mipx_ctx_sync', 'mipx_problem_create', 'mipx_problem_destroy',
-    'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_lp_solve_multi', 'mipx_dev_alloc', 'mipx_dev_free',
+    'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_lp_solve_multi', 'mipx_gomory_batch', 'mipx_dev_alloc', 'mipx_dev_free',
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
     'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
@@ -80,6 +80,7 @@ def lib():
     L.mipx_lp_solve_batch.argtypes = solve_args
     L.mipx_lp_solve_batch_dev.argtypes = solve_args
     L.mipx_lp_solve_multi.argtypes = [_vp, C.c_int, C.c_int, C.c_int] + [_vp] * 5 + [C.c_int] + [_vp] * 6
+    L.mipx_gomory_batch.argtypes = [_vp, C.c_int] + [_vp] * 5 + [C.c_double] + [_vp] * 6
     L.mipx_dev_alloc.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
     L.mipx_dev_free.argtypes = [_vp, _vp]
     L.mipx_memcpy_h2d.argtypes = [_vp, _vp, _vp, C.c_size_t]
@@ -232,6 +233,27 @@ class Problem:
                                        _ptr(iters), _ptr(npiv))
         self.ctx.check(rc, 'mipx_lp_solve_batch')
         return dict(status=status, obj=obj, x=x, y=y, vstat=vout, iters=iters, npivots=npiv)
+
+    def gomory_batch(self, l, u, vstat, x, integer_indices, max_term=1e3):
+        """GMI cuts + safe rounding for solved nodes; list (one per node) of dicts with
+        row_idx, pi, pi0, safe_pi, safe_pi0 (one row per cut)."""
+        n, m = self.n, self.m
+        l = np.ascontiguousarray(l, dtype=np.float64).reshape(-1, n)
+        B = l.shape[0]
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(B, n)
+        vstat = np.ascontiguousarray(vstat, dtype=np.int8).reshape(B, n + m)
+        x = np.ascontiguousarray(np.maximum(np.asarray(x, dtype=np.float64), 0)).reshape(B, n)
+        is_int = np.zeros(n, np.uint8)
+        is_int[np.asarray(integer_indices, dtype=int)] = 1
+        ncuts = np.zeros(B, np.int32); row_idx = np.zeros((B, max(m, 1)), np.int32)
+        pi = np.zeros((B, max(m, 1), n)); pi0 = np.zeros((B, max(m, 1)))
+        spi = np.zeros((B, max(m, 1), n)); spi0 = np.zeros((B, max(m, 1)))
+        rc = lib().mipx_gomory_batch(self._h, B, _ptr(l), _ptr(u), _ptr(vstat), _ptr(x),
+                                     _ptr(is_int), float(max_term), _ptr(ncuts), _ptr(row_idx),
+                                     _ptr(pi), _ptr(pi0), _ptr(spi), _ptr(spi0))
+        self.ctx.check(rc, 'mipx_gomory_batch')
+        return [dict(row_idx=row_idx[k, :ncuts[k]], pi=pi[k, :ncuts[k]], pi0=pi0[k, :ncuts[k]],
+                     safe_pi=spi[k, :ncuts[k]], safe_pi0=spi0[k, :ncuts[k]]) for k in range(B)]
 
     def solve_batch_dev(self, B, d_l, d_u, d_vstat, max_iter, d_status, d_obj, d_x, d_y, d_vout,
                         d_iters, d_npiv):

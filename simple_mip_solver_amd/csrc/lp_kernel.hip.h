@@ -51,6 +51,7 @@ struct LpArgs {
     double *dbg_T;      // m x n row-major
     double *dbg_vec;    // [d (n) | beta0 (m) | ba (m) | bb (m)]
     int32_t *dbg_idx;   // [nvar (n) | bvar (m) | side (n)]
+    int dbg_all;        // 0: node 0 only; 1: every node k at offsets k*m*n, k*(n+3m), k*(2n+m)
 };
 
 // ---- wavefront-wide reductions on DPP (row_shr prefix-doubling inside each row of 16 lanes,
@@ -589,25 +590,29 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
             for (int i = tid; i < m; i += NT) vo[s.bvar[i]] = 1;
             for (int j = tid; j < n; j += NT) vo[s.nvar[j]] = s.side[j] ? 2 : 3;
         }
-        if (g.dbg_T && node == 0) {
+        if (g.dbg_T && (node == 0 || g.dbg_all)) {
+            const size_t k = g.dbg_all ? (size_t)node : 0;
+            double *dT = g.dbg_T + k * (size_t)m * n;
+            double *dvec = g.dbg_vec + k * (size_t)(n + 3 * m);
+            int32_t *didx = g.dbg_idx + k * (size_t)(2 * n + m);
 #pragma unroll
             for (int ii = 0; ii < R; ii++) {
 #pragma unroll
                 for (int jj = 0; jj < C; jj++) {
                     const int i = bi + TBI * ii, j = bj + TBJ * jj;
-                    if (i < m && j < n) g.dbg_T[(size_t)i * n + j] = T[ii][jj];
+                    if (i < m && j < n) dT[(size_t)i * n + j] = T[ii][jj];
                 }
             }
             for (int j = tid; j < n; j += NT) {
-                g.dbg_vec[j] = s.d[j];
-                g.dbg_idx[j] = s.nvar[j];
-                g.dbg_idx[n + m + j] = s.side[j];
+                dvec[j] = s.d[j];
+                didx[j] = s.nvar[j];
+                didx[n + m + j] = s.side[j];
             }
             for (int i = tid; i < m; i += NT) {
-                g.dbg_vec[n + i] = s.beta0[i];
-                g.dbg_vec[n + m + i] = s.ba[i];
-                g.dbg_vec[n + 2 * m + i] = s.bb[i];
-                g.dbg_idx[n + i] = s.bvar[i];
+                dvec[n + i] = s.beta0[i];
+                dvec[n + m + i] = s.ba[i];
+                dvec[n + 2 * m + i] = s.bb[i];
+                didx[n + i] = s.bvar[i];
             }
         }
         if (tid < 64) {

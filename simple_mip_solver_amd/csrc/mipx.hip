@@ -80,6 +80,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 }  // namespace
 
 #include "tree_engine.hip.h"
+#include "cut_kernels.hip.h"
 
 extern "C" {
 
@@ -189,7 +190,7 @@ int mipx_lp_solve_batch_dev(mipx_problem *p, int batch, const double *l, const d
     a.l = l; a.u = u; a.vstat_in = vstat_in; a.slot = nullptr; a.max_iter = max_iter;
     a.status = status; a.obj = obj; a.x = x; a.y = y; a.vstat_out = vstat_out;
     a.iters = iters; a.npivots = npivots; a.batch = batch;
-    a.dbg_T = p->dbg_T; a.dbg_vec = p->dbg_vec; a.dbg_idx = p->dbg_idx;
+    a.dbg_T = p->dbg_T; a.dbg_vec = p->dbg_vec; a.dbg_idx = p->dbg_idx; a.dbg_all = 0;
     cfg->launch(a, batch, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return MIPX_OK;
@@ -302,7 +303,7 @@ int mipx_lp_solve_multi(mipx_ctx *ctx, int m, int n, int batch, const double *A,
         a.status = (int32_t *)(base + o_st); a.obj = (double *)(base + o_obj);
         a.x = (double *)(base + o_x); a.y = nullptr; a.vstat_out = (int8_t *)(base + o_v);
         a.iters = (int32_t *)(base + o_it); a.npivots = (int32_t *)(base + o_np); a.batch = batch;
-        a.dbg_T = nullptr; a.dbg_vec = nullptr; a.dbg_idx = nullptr;
+        a.dbg_T = nullptr; a.dbg_vec = nullptr; a.dbg_idx = nullptr; a.dbg_all = 0;
         cfg->launch(a, batch, st);
         if (hipGetLastError() != hipSuccess) rc = fail(ctx, MIPX_EHIP, "mipx_lp_solve_multi: launch");
     }
@@ -313,6 +314,73 @@ int mipx_lp_solve_multi(mipx_ctx *ctx, int m, int n, int batch, const double *A,
     down(status, o_st, B * 4); down(obj, o_obj, B * 8); down(x, o_x, B * nn * 8);
     down(vstat_out, o_v, B * nv); down(iters, o_it, B * 4); down(npivots, o_np, B * 4);
     if (hipStreamSynchronize(st) != hipSuccess && rc == MIPX_OK) rc = fail(ctx, MIPX_EHIP, "mipx_lp_solve_multi: sync");
+    (void)hipFree(base);
+    return rc;
+}
+
+int mipx_gomory_batch(mipx_problem *p, int batch, const double *l, const double *u,
+                      const int8_t *vstat, const double *x, const uint8_t *is_int, double max_term,
+                      int32_t *ncuts, int32_t *row_idx, double *pi, double *pi0, double *safe_pi,
+                      double *safe_pi0) {
+    if (!p) return MIPX_EINVAL;
+    mipx_ctx *ctx = p->ctx;
+    if (batch < 0 || (batch && (!l || !u || !vstat || !x || !is_int || !ncuts)))
+        return fail(ctx, MIPX_EINVAL, "mipx_gomory_batch: bad argument");
+    if (batch == 0) return MIPX_OK;
+    const KernelCfg *cfg = pick_cfg(p->m, p->n);
+    if (!cfg) return fail(ctx, MIPX_ETOOBIG, "mipx_gomory_batch: (m,n) too big");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t B = (size_t)batch, n = (size_t)p->n, m = (size_t)(p->m ? p->m : 1), nv = n + p->m;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_l = carve(B * n * 8), o_u = carve(B * n * 8), o_v = carve(B * nv),
+                 o_x = carve(B * n * 8), o_int = carve(n), o_T = carve(B * m * n * 8),
+                 o_vec = carve(B * (n + 3 * m) * 8), o_idx = carve(B * (2 * n + m) * 4),
+                 o_nc = carve(B * 4), o_ri = carve(B * m * 4), o_pi = carve(B * m * n * 8),
+                 o_p0 = carve(B * m * 8), o_sp = carve(B * m * n * 8), o_s0 = carve(B * m * 8);
+    char *base = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&base, off));
+    hipStream_t st = ctx->stream;
+    int rc = MIPX_OK;
+    auto up = [&](size_t o, const void *src, size_t bytes) {
+        if (rc == MIPX_OK && hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+            rc = fail(ctx, MIPX_EHIP, "mipx_gomory_batch: upload");
+    };
+    up(o_l, l, B * n * 8); up(o_u, u, B * n * 8); up(o_v, vstat, B * nv); up(o_x, x, B * n * 8);
+    up(o_int, is_int, n);
+    if (rc == MIPX_OK) {
+        // K1 from the given (optimal) basis: refactorises and leaves T / bvar / nvar in HBM
+        mipx::LpArgs a;
+        a.m = p->m; a.n = p->n;
+        a.A = p->dA; a.b = p->db; a.c = p->dc;
+        a.A_stride = a.b_stride = a.c_stride = 0;
+        a.l = (const double *)(base + o_l); a.u = (const double *)(base + o_u);
+        a.vstat_in = (const int8_t *)(base + o_v); a.slot = nullptr; a.max_iter = 0;
+        a.status = nullptr; a.obj = nullptr; a.x = nullptr; a.y = nullptr; a.vstat_out = nullptr;
+        a.iters = nullptr; a.npivots = nullptr; a.batch = batch;
+        a.dbg_T = (double *)(base + o_T); a.dbg_vec = (double *)(base + o_vec);
+        a.dbg_idx = (int32_t *)(base + o_idx); a.dbg_all = 1;
+        cfg->launch(a, batch, st);
+        mipx::GomoryArgs g;
+        g.m = p->m; g.n = p->n; g.batch = batch;
+        g.A = p->dA; g.b = p->db;
+        g.T = (const double *)(base + o_T); g.idx = (const int32_t *)(base + o_idx);
+        g.x = (const double *)(base + o_x); g.is_int = (const uint8_t *)(base + o_int);
+        g.max_term = max_term;
+        g.ncuts = (int32_t *)(base + o_nc); g.row_idx = (int32_t *)(base + o_ri);
+        g.pi = (double *)(base + o_pi); g.pi0 = (double *)(base + o_p0);
+        g.safe_pi = (double *)(base + o_sp); g.safe_pi0 = (double *)(base + o_s0);
+        const size_t lds = (n + (size_t)p->m + 64) * 8 + (2 * (size_t)p->m + n) * 4 + 64;
+        hipLaunchKernelGGL((mipx::gomory_cuts<256>), dim3(batch), dim3(256), lds, st, g);
+        if (hipGetLastError() != hipSuccess) rc = fail(ctx, MIPX_EHIP, "mipx_gomory_batch: launch");
+    }
+    auto down = [&](void *dst, size_t o, size_t bytes) {
+        if (dst && rc == MIPX_OK && hipMemcpyAsync(dst, base + o, bytes, hipMemcpyDeviceToHost, st) != hipSuccess)
+            rc = fail(ctx, MIPX_EHIP, "mipx_gomory_batch: download");
+    };
+    down(ncuts, o_nc, B * 4); down(row_idx, o_ri, B * m * 4); down(pi, o_pi, B * m * n * 8);
+    down(pi0, o_p0, B * m * 8); down(safe_pi, o_sp, B * m * n * 8); down(safe_pi0, o_s0, B * m * 8);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == MIPX_OK) rc = fail(ctx, MIPX_EHIP, "mipx_gomory_batch: sync");
     (void)hipFree(base);
     return rc;
 }

@@ -162,7 +162,7 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
     a.l = l; a.u = u; a.vstat_in = v; a.slot = slot; a.max_iter = max_iter;
     a.status = status; a.obj = obj; a.x = x; a.y = nullptr; a.vstat_out = vout;
     a.iters = iters; a.npivots = npiv; a.batch = batch;
-    a.dbg_T = nullptr; a.dbg_vec = nullptr; a.dbg_idx = nullptr;
+    a.dbg_T = nullptr; a.dbg_vec = nullptr; a.dbg_idx = nullptr; a.dbg_all = 0;
     cfg->launch(a, batch, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
     return MIPX_OK;
