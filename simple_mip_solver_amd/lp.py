@@ -147,6 +147,11 @@ class LPBackend:
     def solve(self, A, b, c, l, u, vstat, max_iter, cache_key):
         raise NotImplementedError
 
+    def gomory(self, A, b, c, l, u, vstat, x, integer_indices, max_term, cache_key):
+        """Raw and safely rounded GMI cuts of one solved node, or None if the engine has no
+        cut kernel (the node then uses its host arithmetic)."""
+        return None
+
 
 class HipBackend(LPBackend):
     """Sends the solve to libmipx.so on the MI355X (no fallback)."""
@@ -176,6 +181,10 @@ class HipBackend(LPBackend):
     def solve(self, A, b, c, l, u, vstat, max_iter, cache_key):
         """l, u: (batch, n); vstat (batch, n+m) or None.  Returns dict of batch arrays."""
         return self._problem(A, b, c, cache_key).solve_batch(l, u, vstat, max_iter)
+
+    def gomory(self, A, b, c, l, u, vstat, x, integer_indices, max_term, cache_key):
+        return self._problem(A, b, c, cache_key).gomory_batch(
+            l[None], u[None], vstat[None], x[None], integer_indices, max_term)[0]
 
 
 _backend = None
@@ -414,6 +423,17 @@ class DenseLP:
         return self._status
 
     primal = dual  # the engine has one algorithm; results (status/objective/solution) are the same
+
+    def gomory_rows(self, x, integer_indices, max_term):
+        """GMI cuts of the current (optimal) basis from the engine's cut kernel, in the LP's own
+        row numbering; None if the backend has none or the rows are not all plain `>=` rows."""
+        rs = self._engine_form()
+        if self._var_status is None or any(sign < 0 for _, _, sign in self._rowmap) or \
+                len(self._rowmap) != self.nConstraints:
+            return None
+        l, u = self._bounds()
+        return get_backend().gomory(rs.A, rs.b, rs.c, l, u, self._warm_start(rs)[0],
+                                    np.asarray(x, dtype=np.float64), integer_indices, max_term, rs.key)
 
     def _store(self, res, k):
         n = self.nVariables

@@ -87,6 +87,7 @@ class BaseNode:
             setattr(self, f'iterations_gmic_{op}', 0)
             setattr(self, f'number_gmic_{op}', 0)
         self._cut_pool = {}
+        self._engine_rounded = {}
         first_block = lp.constraints[0]
         self.max_term = np.max(np.abs(first_block.varCoefs[lp.getVarByName('x')]))
 
@@ -272,9 +273,14 @@ class BaseNode:
         assert isinstance(gomory_cuts, bool), 'gomory_cuts is boolean'
         pool = {}
         if gomory_cuts:
+            self._engine_rounded = {}
             for row, (pi, pi0) in self._find_gomory_cuts().items():
                 name = f'cut_gomory_{self.idx}_{self.cut_generation_iterations}_{row}'
-                pool[name] = numerically_safe_cut(pi=pi, pi0=pi0, estimate='over')
+                ready = self._engine_rounded.get(row)
+                if ready is not None and ready[0] is pi:
+                    pool[name] = ready[1]   # rounded by the cut kernel together with the row
+                else:
+                    pool[name] = numerically_safe_cut(pi=pi, pi0=pi0, estimate='over')
             self._update_gmic_counts(cut_idxs=pool, operation='created')
         return pool
 
@@ -338,6 +344,19 @@ class BaseNode:
         """Gomory mixed-integer cuts from the optimal tableau, slack variables substituted out
         (reference :468-511).  Returns {tableau row: (pi, pi0)} meaning pi.x >= pi0."""
         cuts = {}
+        if len(self.basic_variable_indices) != self.lp.nConstraints:
+            return cuts  # not a square basis: the reference's tableau is None here (:518-519)
+        from_engine = self.lp.gomory_rows(self.solution, self._integer_indices, tol.max_term)
+        if from_engine is not None:
+            # K2 on the MI355X: tableau rows, GMI coefficients, slack substitution and the safe
+            # rounding in one launch (the rounded form is handed to _generate_cuts)
+            self._engine_rounded = {}
+            for k, row in enumerate(from_engine['row_idx']):
+                pi = CyLPArray(from_engine['pi'][k])
+                cuts[int(row)] = (pi, float(from_engine['pi0'][k]))
+                self._engine_rounded[int(row)] = (pi, (CyLPArray(from_engine['safe_pi'][k]),
+                                                       float(from_engine['safe_pi0'][k])))
+            return cuts
         tableau = self.tableau
         if tableau is None:
             return cuts

@@ -27,3 +27,11 @@ class CompareBackend(HipBackend):
         for key in ('x', 'obj', 'y'):
             assert np.array_equal(g[key][fin], o[key][fin]), f'engine/oracle mismatch in {key}'
         return g
+
+    def gomory(self, A, b, c, l, u, vstat, x, integer_indices, max_term, cache_key):
+        g = super().gomory(A, b, c, l, u, vstat, x, integer_indices, max_term, cache_key)
+        o = O.gomory(A, b, c, l, u, vstat, x, integer_indices, max_term)
+        assert np.array_equal(g['row_idx'], o['row_idx']), 'engine/oracle Gomory rows differ'
+        for key in ('pi', 'pi0', 'safe_pi', 'safe_pi0'):
+            assert np.array_equal(g[key], o[key]), f'engine/oracle mismatch in Gomory {key}'
+        return g

@@ -18,3 +18,6 @@ class OracleBackend(LPBackend):
         self.calls += 1
         self.lps += len(l)
         return O.lp_solve_batch(A, b, c, l, u, vstat, max_iter)
+
+    def gomory(self, A, b, c, l, u, vstat, x, integer_indices, max_term, cache_key):
+        return O.gomory(A, b, c, l, u, vstat, x, integer_indices, max_term)
