@@ -125,6 +125,25 @@ int mipx_gomory_batch(mipx_problem *p, int batch, const double *l, const double 
                       int32_t *ncuts, int32_t *row_idx, double *pi, double *pi0, double *safe_pi,
                       double *safe_pi0);
 
+/*
+ * Batched cut selection: replaces the arithmetic of BaseNode._select_cuts (base_node.py:414-452).
+ *   npool       batch            cuts in each node's pool (<= kmax)
+ *   pi, pi0     batch x kmax x n, batch x kmax   the pools (rows beyond npool ignored)
+ *   x           batch x n        the nodes' LP solutions
+ *   max_nonzero_coefs, min_cut_depth               as the reference's keyword arguments
+ *   cos_parallel    cos(radians(parallel_cut_tolerance)): a cut closer than that to an added one is skipped
+ *   max_abs_coef    max_relative_cut_term_ratio * node.max_term
+ *   nadded, added   batch, batch x kmax   pool positions in the order the cuts are added to the LP
+ *   terminator      batch   0 none, 1 'no cuts', 2 'no improving cuts', 3 'no sufficient cuts'
+ *   depth           batch x kmax (may be NULL)  euclidean depth per pool cut, +inf if not a candidate
+ * HOST pointers.
+ */
+int mipx_cut_select_batch(mipx_ctx *ctx, int n, int batch, int kmax, const int32_t *npool,
+                          const double *pi, const double *pi0, const double *x,
+                          int max_nonzero_coefs, double min_cut_depth, double cos_parallel,
+                          double max_abs_coef, int32_t *nadded, int32_t *added, int32_t *terminator,
+                          double *depth);
+
 /* Device memory owned by the library, for the device-resident entry points. */
 int mipx_dev_alloc(mipx_ctx *ctx, size_t bytes, void **dptr);
 int mipx_dev_free(mipx_ctx *ctx, void *dptr);

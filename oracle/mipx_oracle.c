@@ -593,3 +593,63 @@ int mipx_oracle_gomory(int m, int n, const double *A, const double *b, const dou
     free(order); free(pv); free(ps); free(buf);
     return ncuts;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Cut selection (base_node.py:387-466): candidates = pool cuts with 0 < support <= max_nonzero
+ * (support counts |pi_j| > 1e-2); depth = (pi.x - pi0)/||pi|| with fold-in-half sums; greedy in
+ * ascending depth (stable): stop at depth >= -min_cut_depth, skip max|pi| > max_abs_coef, skip
+ * if cos(angle to an added cut) > cos_parallel.  terminator: 0 none, 1 'no cuts',
+ * 2 'no improving cuts', 3 'no sufficient cuts'.  Returns the number added.
+ * ---------------------------------------------------------------------------------------- */
+static double fold_dot(const double *a, const double *b, int n, int n2, double *buf) {
+    for (int j = 0; j < n; j++) buf[j] = a[j] * b[j];
+    for (int j = n; j < n2; j++) buf[j] = 0.0;
+    return fold_sum(buf, n2);
+}
+
+int mipx_oracle_select_cuts(int n, int K, const double *pi, const double *pi0, const double *x,
+                            int max_nonzero_coefs, double min_cut_depth, double cos_parallel,
+                            double max_abs_coef, int32_t *added, int32_t *terminator, double *depth) {
+    int n2 = 64;
+    while (n2 < n) n2 <<= 1;
+    double *buf = (double *)malloc(sizeof(double) * (size_t)n2);
+    double *nrm = (double *)malloc(sizeof(double) * (size_t)(K + 1));
+    double *mab = (double *)malloc(sizeof(double) * (size_t)(K + 1));
+    int *ord = (int *)malloc(sizeof(int) * (size_t)(K + 1));
+    int ncand = 0;
+    for (int k = 0; k < K; k++) {
+        const double *pk = pi + (size_t)k * n;
+        int sup = 0; double mx = 0.0;
+        for (int j = 0; j < n; j++) { sup += (pk[j] > 1e-2) + (pk[j] < -1e-2); mx = fmax(mx, fabs(pk[j])); }
+        const double dot = fold_dot(pk, x, n, n2, buf);
+        const double sq = fold_dot(pk, pk, n, n2, buf);
+        nrm[k] = sqrt(sq); mab[k] = mx;
+        depth[k] = (sup > 0 && sup <= max_nonzero_coefs) ? (dot - pi0[k]) / nrm[k] : INFINITY;
+    }
+    for (int k = 0; k < K; k++) {
+        if (isinf(depth[k]) && depth[k] > 0) continue;
+        int rank = 0;
+        for (int q = 0; q < K; q++)
+            if (!(isinf(depth[q]) && depth[q] > 0) && (depth[q] < depth[k] || (depth[q] == depth[k] && q < k))) rank++;
+        ord[rank] = k; ncand++;
+    }
+    *terminator = 0;
+    if (ncand == 0) *terminator = 1;
+    else if (depth[ord[0]] >= 0.0) *terminator = 2;
+    else if (depth[ord[0]] >= -min_cut_depth) *terminator = 3;
+    int nadd = 0;
+    for (int c = 0; c < ncand; c++) {
+        const int k = ord[c];
+        if (depth[k] >= -min_cut_depth) break;
+        if (mab[k] > max_abs_coef) continue;
+        int parallel = 0;
+        for (int a = 0; a < nadd && !parallel; a++) {
+            double cs = fold_dot(pi + (size_t)k * n, pi + (size_t)added[a] * n, n, n2, buf) / (nrm[k] * nrm[added[a]]);
+            cs = fmin(1.0, fmax(-1.0, cs));
+            if (cs > cos_parallel) parallel = 1;
+        }
+        if (!parallel) added[nadd++] = k;
+    }
+    free(buf); free(nrm); free(mab); free(ord);
+    return nadd;
+}

@@ -164,3 +164,18 @@ def gomory(A, b, c, l, u, vstat, x, int_idx, max_term=1e3):
                                  _p(row_idx, _i32p), _p(pi, _dp), _p(pi0, _dp), _p(spi, _dp),
                                  _p(spi0, _dp))
     return dict(row_idx=row_idx[:k], pi=pi[:k], pi0=pi0[:k], safe_pi=spi[:k], safe_pi0=spi0[:k])
+
+
+def select_cuts(pi, pi0, x, max_nonzero_coefs, min_cut_depth, cos_parallel, max_abs_coef):
+    """Greedy cut selection; returns (added positions in order, terminator code, depths)."""
+    pi = np.ascontiguousarray(pi, np.float64).reshape(len(pi0), -1) if len(pi0) else np.zeros((0, len(x)))
+    K, n = pi.shape
+    pi0 = np.ascontiguousarray(pi0, np.float64); x = np.ascontiguousarray(x, np.float64)
+    added = np.zeros(max(K, 1), np.int32); term = C.c_int32(); depth = np.zeros(max(K, 1))
+    lib().mipx_oracle_select_cuts.restype = C.c_int
+    k = lib().mipx_oracle_select_cuts(C.c_int(n), C.c_int(K), _p(pi, _dp), _p(pi0, _dp), _p(x, _dp),
+                                      C.c_int(int(min(max_nonzero_coefs, 2**31 - 1))),
+                                      C.c_double(min_cut_depth), C.c_double(cos_parallel),
+                                      C.c_double(max_abs_coef), _p(added, _i32p), C.byref(term),
+                                      _p(depth, _dp))
+    return added[:k].copy(), int(term.value), depth[:K].copy()

@@ -18,7 +18,7 @@ ERRORS = {-1: 'MIPX_EINVAL', -2: 'MIPX_ENODEV', -3: 'MIPX_EHIP', -4: 'MIPX_ETOOB
 SYMBOLS = [
     'mipx_abi_version', 'mipx_device_count', 'mipx_ctx_create', 'mipx_ctx_destroy',
     'mipx_last_error', 'mipx_ctx_sync', 'mipx_problem_create', 'mipx_problem_destroy',
-    'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_lp_solve_multi', 'mipx_gomory_batch', 'mipx_dev_alloc', 'mipx_dev_free',
+    'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_lp_solve_multi', 'mipx_gomory_batch', 'mipx_cut_select_batch', 'mipx_dev_alloc', 'mipx_dev_free',
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
     'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
@@ -81,6 +81,8 @@ def lib():
     L.mipx_lp_solve_batch_dev.argtypes = solve_args
     L.mipx_lp_solve_multi.argtypes = [_vp, C.c_int, C.c_int, C.c_int] + [_vp] * 5 + [C.c_int] + [_vp] * 6
     L.mipx_gomory_batch.argtypes = [_vp, C.c_int] + [_vp] * 5 + [C.c_double] + [_vp] * 6
+    L.mipx_cut_select_batch.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int,
+                                        C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp]
     L.mipx_dev_alloc.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
     L.mipx_dev_free.argtypes = [_vp, _vp]
     L.mipx_memcpy_h2d.argtypes = [_vp, _vp, _vp, C.c_size_t]
@@ -176,6 +178,25 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def select_cuts(ctx, pi, pi0, x, max_nonzero_coefs, min_cut_depth, cos_parallel, max_abs_coef):
+    """K3 for ONE node: (added pool positions in order, terminator code, depths)."""
+    pi0 = np.ascontiguousarray(pi0, dtype=np.float64).reshape(-1)
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+    K, n = len(pi0), len(x)
+    kmax = max(K, 1)
+    P = np.zeros((kmax, n)); P0 = np.zeros(kmax)
+    if K:
+        P[:K] = np.asarray(pi, dtype=np.float64).reshape(K, n); P0[:K] = pi0
+    npool = np.array([K], np.int32); nadded = np.zeros(1, np.int32); added = np.zeros(kmax, np.int32)
+    term = np.zeros(1, np.int32); depth = np.zeros(kmax)
+    rc = lib().mipx_cut_select_batch(ctx._h, n, 1, kmax, _ptr(npool), _ptr(P), _ptr(P0), _ptr(x),
+                                     int(min(max_nonzero_coefs, 2 ** 31 - 1)), float(min_cut_depth),
+                                     float(cos_parallel), float(max_abs_coef), _ptr(nadded),
+                                     _ptr(added), _ptr(term), _ptr(depth))
+    ctx.check(rc, 'mipx_cut_select_batch')
+    return added[:nadded[0]].copy(), int(term[0]), depth[:K].copy()
 
 
 def solve_multi(ctx, A, b, c, l, u, max_iter=0):

@@ -231,3 +231,130 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
 }
 
 }  // namespace mipx
+
+namespace mipx {
+
+// ---- K3: cut selection (reference base_node.py:387-466) -----------------------------------------
+// One workgroup (256 threads) per node.  Per pool cut: support count, euclidean depth of the
+// violation, norm and largest |coefficient| (fold-in-half sums over the padded power of two);
+// then the reference's greedy pass in ascending depth (stable), with the parallelism test done as
+// cos(angle) > cos(parallel_cut_tolerance) instead of acos (same predicate, no libm dependence).
+struct SelectArgs {
+    int n, batch, kmax;           // kmax: pool rows allotted per node
+    const int32_t *npool;         // batch: cuts in each node's pool
+    const double *pi, *pi0;       // batch x kmax x n, batch x kmax
+    const double *x;              // batch x n
+    int max_nonzero_coefs;
+    double min_cut_depth, cos_parallel, max_abs_coef;  // max_relative_cut_term_ratio * max_term
+    int32_t *nadded;              // batch
+    int32_t *added;               // batch x kmax: pool positions in the order they are added
+    int32_t *terminator;          // batch: 0 none, 1 'no cuts', 2 'no improving cuts', 3 'no sufficient cuts'
+    double *depth;                // batch x kmax (NaN-free: +inf for cuts that are not candidates)
+};
+
+// fold-in-half sum of f(j) over j < n2 (power of two, >= 64) by one wave; result in every lane
+template <typename F>
+__device__ inline double wave_fold(int n2, int lane, F f) {
+    double e[16];
+    const int per = n2 / 64;  // <= 16 (n <= 1024)
+#pragma unroll
+    for (int k = 0; k < 16; k++) e[k] = k < per ? f(lane + 64 * k) : 0.0;
+    for (int h = per / 2; h >= 1; h >>= 1)
+        for (int k = 0; k < h; k++) e[k] = e[k] + e[k + h];
+    double s = e[0];
+    for (int h = 32; h >= 1; h >>= 1) s = s + __shfl_down(s, h, 64);
+    return __shfl(s, 0, 64);
+}
+
+__global__ __launch_bounds__(256) void select_cuts(SelectArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int node = blockIdx.x;
+    if (node >= g.batch) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = g.n, K = g.npool[node];
+    const double INF = __builtin_huge_val();
+    double *dep = (double *)smem_raw;   // K
+    double *nrm = dep + g.kmax;         // K
+    double *mab = nrm + g.kmax;         // K
+    int *ord = (int *)(mab + g.kmax);   // K: candidates in ascending depth (stable)
+    int *add = ord + g.kmax;            // K
+    int *cnt = add + g.kmax;            // [ncand, nadded]
+    int n2 = 64;
+    while (n2 < n) n2 <<= 1;
+    const double *P = g.pi + (size_t)node * g.kmax * n;
+    const double *x = g.x + (size_t)node * n;
+    // per-cut statistics, one wave per cut
+    for (int k = wave; k < K; k += 4) {
+        const double *pk = P + (size_t)k * n;
+        int sup = 0;
+        double mx = 0.0;
+        for (int j = lane; j < n; j += 64) {
+            const double v = pk[j];
+            sup += (v > kGoodEps) + (v < -kGoodEps);
+            mx = fmax(mx, fabs(v));
+        }
+        for (int h = 32; h >= 1; h >>= 1) sup += __shfl_down(sup, h, 64);
+        sup = __shfl(sup, 0, 64);
+        mx = wave_max_f64(mx);
+        const double dot = wave_fold(n2, lane, [&](int j) { return j < n ? pk[j] * x[j] : 0.0; });
+        const double sq = wave_fold(n2, lane, [&](int j) { return j < n ? pk[j] * pk[j] : 0.0; });
+        if (lane == 0) {
+            const double nr = sqrt(sq);
+            nrm[k] = nr;
+            mab[k] = mx;
+            dep[k] = (sup > 0 && sup <= g.max_nonzero_coefs) ? (dot - g.pi0[(size_t)node * g.kmax + k]) / nr : INF;
+        }
+    }
+    __syncthreads();
+    // stable ascending order of the candidates (rank = #smaller + #equal-before)
+    if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+        if (dep[k] == INF) continue;
+        int rank = 0;
+        for (int q = 0; q < K; q++)
+            if (dep[q] != INF && (dep[q] < dep[k] || (dep[q] == dep[k] && q < k))) rank++;
+        ord[rank] = k;
+        atomicAdd(&cnt[0], 1);
+    }
+    __syncthreads();
+    const int ncand = cnt[0];
+    int term = 0;
+    if (ncand == 0) term = 1;
+    else if (dep[ord[0]] >= 0.0) term = 2;
+    else if (dep[ord[0]] >= -g.min_cut_depth) term = 3;
+    // greedy pass: sequential over candidates, each test parallel over the cuts already added
+    int nadd = 0;
+    for (int c = 0; c < ncand; c++) {
+        const int k = ord[c];
+        if (dep[k] >= -g.min_cut_depth) break;
+        if (mab[k] > g.max_abs_coef) continue;
+        const double *pk = P + (size_t)k * n;
+        // dot products with the added cuts: one wave per added cut
+        __syncthreads();
+        if (tid == 0) cnt[1] = 0;
+        __syncthreads();
+        for (int a = wave; a < nadd; a += 4) {
+            const double *pa = P + (size_t)add[a] * n;
+            const double dot = wave_fold(n2, lane, [&](int j) { return j < n ? pk[j] * pa[j] : 0.0; });
+            if (lane == 0) {
+                double cs = dot / (nrm[k] * nrm[add[a]]);
+                cs = fmin(1.0, fmax(-1.0, cs));
+                if (cs > g.cos_parallel) atomicAdd(&cnt[1], 1);
+            }
+        }
+        __syncthreads();
+        if (cnt[1] == 0) {
+            if (tid == 0) add[nadd] = k;
+            nadd++;
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < g.kmax; k += 256) {
+        g.depth[(size_t)node * g.kmax + k] = k < K ? dep[k] : INF;
+        if (k < nadd) g.added[(size_t)node * g.kmax + k] = add[k];
+    }
+    if (tid == 0) { g.nadded[node] = nadd; g.terminator[node] = term; }
+}
+
+}  // namespace mipx

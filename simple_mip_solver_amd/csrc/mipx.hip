@@ -385,6 +385,57 @@ int mipx_gomory_batch(mipx_problem *p, int batch, const double *l, const double 
     return rc;
 }
 
+int mipx_cut_select_batch(mipx_ctx *ctx, int n, int batch, int kmax, const int32_t *npool,
+                          const double *pi, const double *pi0, const double *x,
+                          int max_nonzero_coefs, double min_cut_depth, double cos_parallel,
+                          double max_abs_coef, int32_t *nadded, int32_t *added, int32_t *terminator,
+                          double *depth) {
+    if (!ctx || n <= 0 || n > 1024 || batch < 0 || kmax < 1 ||
+        (batch && (!npool || !pi || !pi0 || !x || !nadded || !added || !terminator)))
+        return fail(ctx, MIPX_EINVAL, "mipx_cut_select_batch: bad argument");
+    if (batch == 0) return MIPX_OK;
+    for (int k = 0; k < batch; k++)
+        if (npool[k] < 0 || npool[k] > kmax) return fail(ctx, MIPX_EINVAL, "mipx_cut_select_batch: npool out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t B = (size_t)batch, nn = (size_t)n, K = (size_t)kmax;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_np = carve(B * 4), o_pi = carve(B * K * nn * 8), o_p0 = carve(B * K * 8),
+                 o_x = carve(B * nn * 8), o_na = carve(B * 4), o_ad = carve(B * K * 4),
+                 o_te = carve(B * 4), o_de = carve(B * K * 8);
+    char *base = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&base, off));
+    hipStream_t st = ctx->stream;
+    int rc = MIPX_OK;
+    auto up = [&](size_t o, const void *src, size_t bytes) {
+        if (rc == MIPX_OK && hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+            rc = fail(ctx, MIPX_EHIP, "mipx_cut_select_batch: upload");
+    };
+    up(o_np, npool, B * 4); up(o_pi, pi, B * K * nn * 8); up(o_p0, pi0, B * K * 8); up(o_x, x, B * nn * 8);
+    if (rc == MIPX_OK) {
+        mipx::SelectArgs g;
+        g.n = n; g.batch = batch; g.kmax = kmax;
+        g.npool = (const int32_t *)(base + o_np); g.pi = (const double *)(base + o_pi);
+        g.pi0 = (const double *)(base + o_p0); g.x = (const double *)(base + o_x);
+        g.max_nonzero_coefs = max_nonzero_coefs; g.min_cut_depth = min_cut_depth;
+        g.cos_parallel = cos_parallel; g.max_abs_coef = max_abs_coef;
+        g.nadded = (int32_t *)(base + o_na); g.added = (int32_t *)(base + o_ad);
+        g.terminator = (int32_t *)(base + o_te); g.depth = (double *)(base + o_de);
+        const size_t lds = K * (3 * 8 + 2 * 4) + 16 + 64;
+        hipLaunchKernelGGL(mipx::select_cuts, dim3(batch), dim3(256), lds, st, g);
+        if (hipGetLastError() != hipSuccess) rc = fail(ctx, MIPX_EHIP, "mipx_cut_select_batch: launch");
+    }
+    auto down = [&](void *dst, size_t o, size_t bytes) {
+        if (dst && rc == MIPX_OK && hipMemcpyAsync(dst, base + o, bytes, hipMemcpyDeviceToHost, st) != hipSuccess)
+            rc = fail(ctx, MIPX_EHIP, "mipx_cut_select_batch: download");
+    };
+    down(nadded, o_na, B * 4); down(added, o_ad, B * K * 4); down(terminator, o_te, B * 4);
+    down(depth, o_de, B * K * 8);
+    if (hipStreamSynchronize(st) != hipSuccess && rc == MIPX_OK) rc = fail(ctx, MIPX_EHIP, "mipx_cut_select_batch: sync");
+    (void)hipFree(base);
+    return rc;
+}
+
 int mipx_dev_alloc(mipx_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return MIPX_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -152,6 +152,11 @@ class LPBackend:
         cut kernel (the node then uses its host arithmetic)."""
         return None
 
+    def select_cuts(self, pi, pi0, x, max_nonzero_coefs, min_cut_depth, cos_parallel, max_abs_coef):
+        """(added pool positions in order, terminator code, depths) or None if the engine has no
+        selection kernel."""
+        return None
+
 
 class HipBackend(LPBackend):
     """Sends the solve to libmipx.so on the MI355X (no fallback)."""
@@ -185,6 +190,11 @@ class HipBackend(LPBackend):
     def gomory(self, A, b, c, l, u, vstat, x, integer_indices, max_term, cache_key):
         return self._problem(A, b, c, cache_key).gomory_batch(
             l[None], u[None], vstat[None], x[None], integer_indices, max_term)[0]
+
+    def select_cuts(self, pi, pi0, x, max_nonzero_coefs, min_cut_depth, cos_parallel, max_abs_coef):
+        from simple_mip_solver_amd import _ffi
+        return _ffi.select_cuts(self._context(), pi, pi0, x, max_nonzero_coefs, min_cut_depth,
+                                cos_parallel, max_abs_coef)
 
 
 _backend = None

@@ -299,6 +299,34 @@ class BaseNode:
         assert isinstance(max_relative_cut_term_ratio, (int, float)) and \
             0 < max_relative_cut_term_ratio, 'max_relative_cut_term_ratio must be positive'
 
+        from math import cos, radians
+        from simple_mip_solver_amd.lp import get_backend
+        names = list(self.cut_pool)
+        x = self.lp.getVarByName('x')
+        engine = None
+        if len(self.solution) <= 1024:
+            engine = get_backend().select_cuts(
+                np.array([self.cut_pool[k][0] for k in names],
+                         dtype=np.float64).reshape(len(names), len(self.solution)),
+                np.array([self.cut_pool[k][1] for k in names], dtype=np.float64), self.solution,
+                max_nonzero_coefs, min_cut_depth, cos(radians(parallel_cut_tolerance)),
+                max_relative_cut_term_ratio * self.max_term)
+        added = {}
+        if engine is not None:
+            # K3 on the MI355X did the arithmetic (depths, filters, greedy pass); apply its verdict
+            picked, terminator, _ = engine
+            if terminator:
+                self.cut_generation_terminator = ('no cuts', 'no improving cuts',
+                                                  'no sufficient cuts')[terminator - 1]
+            for pos in picked:
+                name = names[int(pos)]
+                pi, pi0 = self.cut_pool[name]
+                self.lp.addConstraint(pi * x >= pi0, name)
+                added[name] = (pi, pi0)
+                del self.cut_pool[name]
+            self._update_gmic_counts(cut_idxs=added, operation='added')
+            return added
+
         eps = tol.good_coefficient_approximation_epsilon
         depth = {}
         for name, (pi, pi0) in self.cut_pool.items():
@@ -315,8 +343,6 @@ class BaseNode:
             elif deepest >= -min_cut_depth:
                 self.cut_generation_terminator = 'no sufficient cuts'
 
-        added = {}
-        x = self.lp.getVarByName('x')
         for name in sorted(depth, key=depth.get):  # most violated first (stable)
             if depth[name] >= -min_cut_depth:
                 break
@@ -326,9 +352,9 @@ class BaseNode:
             norm = np.linalg.norm(pi)
             too_parallel = False
             for other, _ in added.values():
-                cos = np.dot(pi, other) / (norm * np.linalg.norm(other))
-                cos = min(1, max(-1, cos))  # median([-1, cos, 1]) of the reference
-                if degrees(acos(cos)) < parallel_cut_tolerance:
+                cosine = np.dot(pi, other) / (norm * np.linalg.norm(other))
+                cosine = min(1, max(-1, cosine))  # median([-1, cos, 1]) of the reference
+                if degrees(acos(cosine)) < parallel_cut_tolerance:
                     too_parallel = True
                     break
             if too_parallel:

@@ -35,3 +35,10 @@ class CompareBackend(HipBackend):
         for key in ('pi', 'pi0', 'safe_pi', 'safe_pi0'):
             assert np.array_equal(g[key], o[key]), f'engine/oracle mismatch in Gomory {key}'
         return g
+
+    def select_cuts(self, pi, pi0, x, max_nonzero_coefs, min_cut_depth, cos_parallel, max_abs_coef):
+        g = super().select_cuts(pi, pi0, x, max_nonzero_coefs, min_cut_depth, cos_parallel, max_abs_coef)
+        o = O.select_cuts(pi, pi0, x, max_nonzero_coefs, min_cut_depth, cos_parallel, max_abs_coef)
+        assert np.array_equal(g[0], o[0]) and g[1] == o[1] and np.array_equal(g[2], o[2]), \
+            'engine/oracle cut selection differs'
+        return g

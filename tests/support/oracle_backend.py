@@ -21,3 +21,6 @@ class OracleBackend(LPBackend):
 
     def gomory(self, A, b, c, l, u, vstat, x, integer_indices, max_term, cache_key):
         return O.gomory(A, b, c, l, u, vstat, x, integer_indices, max_term)
+
+    def select_cuts(self, pi, pi0, x, max_nonzero_coefs, min_cut_depth, cos_parallel, max_abs_coef):
+        return O.select_cuts(pi, pi0, x, max_nonzero_coefs, min_cut_depth, cos_parallel, max_abs_coef)

@@ -76,3 +76,37 @@ def test_gomory_batch_on_random_roots_and_children(n, m, seed, boxed, gpu_ctx, o
                 # pi.x - pi0 = -1 after the slack substitution.  (The reference applies the same
                 # formula when nonbasics sit at upper bounds, where this does not hold.)
                 assert abs(cuts[k]['pi'][c_] @ xk - cuts[k]['pi0'][c_] + 1.0) < 1e-6
+
+
+def test_select_cuts_matches_oracle_and_reference_vectors(gpu_ctx, oracle):
+    import math
+    names = {0: None, 1: 'no cuts', 2: 'no improving cuts', 3: 'no sufficient cuts'}
+    for rec in GOLD['select_cuts']:
+        kw, pool = rec['kwargs'], rec['pool']
+        keys = list(pool)
+        pi = np.array([pool[k]['pi'] for k in keys], float)
+        pi0 = np.array([pool[k]['pi0'] for k in keys], float)
+        args = (pi, pi0, rec['x'], kw.get('max_nonzero_coefs', 1000000), kw.get('min_cut_depth', 1e-8),
+                math.cos(math.radians(kw.get('parallel_cut_tolerance', 10))),
+                kw.get('max_relative_cut_term_ratio', 1000) * 1.0)
+        ga, gt, gd = _ffi.select_cuts(gpu_ctx, *args)
+        oa, ot, od = oracle.select_cuts(*args)
+        assert np.array_equal(ga, oa) and gt == ot and np.array_equal(gd, od)
+        assert [keys[i] for i in ga] == rec['selected'] and names[gt] == rec['terminator']
+
+
+def test_select_cuts_on_generated_pools(gpu_ctx, oracle):
+    import math
+    rng = np.random.default_rng(11)
+    for trial in range(30):
+        n = int(rng.integers(3, 300)); K = int(rng.integers(0, 40))
+        x = rng.uniform(0, 5, n)
+        pi = rng.uniform(-3, 1, (K, n)) * (rng.random((K, n)) < 0.6)
+        if K > 3:
+            pi[1] = pi[0] * 1.001          # nearly parallel pair
+            pi[2] = 0.0                    # empty support
+        pi0 = rng.uniform(-2 * n, 1, K)
+        args = (pi, pi0, x, int(rng.integers(1, n + 1)), 1e-8, math.cos(math.radians(10)), 1000.0)
+        ga, gt, gd = _ffi.select_cuts(gpu_ctx, *args)
+        oa, ot, od = oracle.select_cuts(*args)
+        assert np.array_equal(ga, oa) and gt == ot and np.array_equal(gd, od), trial
