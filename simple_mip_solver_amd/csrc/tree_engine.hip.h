@@ -261,14 +261,35 @@ int tree_step(mipx_tree *t, int want) {
         std::vector<double> pobj;
         if (total > 0) {
             if (2 * total > t->probe_cap) return fail(ctx, MIPX_ENOMEM, "tree: probe pool exhausted");
+            // probe lists and the probed values: read back only the rows of the nodes that asked
+            // (a handful per step once the table has filled), in bulk during the ramp-up
+            int askers = 0;
+            for (int k = 0; k < B; k++) askers += nprobe[k] > 0;
+            std::vector<double> xall;
             plist.resize((size_t)B * t->n_int);
-            HIP_TRY(ctx, hipMemcpy(plist.data(), t->d_plist, plist.size() * 4, hipMemcpyDeviceToHost));
-            for (int k = 0; k < B; k++)
+            const bool bulk = askers > 64;
+            if (bulk) {
+                HIP_TRY(ctx, hipMemcpy(plist.data(), t->d_plist, plist.size() * 4, hipMemcpyDeviceToHost));
+                xall.resize((size_t)B * n);
+                HIP_TRY(ctx, hipMemcpy(xall.data(), t->d_x, xall.size() * 8, hipMemcpyDeviceToHost));
+            }
+            std::vector<double> xone(n);
+            for (int k = 0; k < B; k++) {
+                if (!nprobe[k]) continue;
+                if (!bulk) {
+                    HIP_TRY(ctx, hipMemcpy(plist.data() + (size_t)k * t->n_int, t->d_plist + (size_t)k * t->n_int,
+                                           (size_t)nprobe[k] * 4, hipMemcpyDeviceToHost));
+                    HIP_TRY(ctx, hipMemcpy(xone.data(), t->d_x + (size_t)k * n, (size_t)n * 8, hipMemcpyDeviceToHost));
+                }
+                const double *xk = bulk ? xall.data() + (size_t)k * n : xone.data();
                 for (int e = 0; e < nprobe[k]; e++) {
+                    const int var = t->int_idx[plist[(size_t)k * t->n_int + e]];
                     pair_pos.push_back(k);
                     pair_slot.push_back(slots[k]);
-                    pair_var.push_back(t->int_idx[plist[(size_t)k * t->n_int + e]]);
+                    pair_var.push_back(var);
+                    xrow.push_back(xk[var]);
                 }
+            }
             const int P = (int)pair_pos.size();
             child_slot.resize(2 * (size_t)P);
             for (int c = 0; c < 2 * P; c++) child_slot[c] = c;
@@ -292,15 +313,9 @@ int tree_step(mipx_tree *t, int want) {
             if (rc) return rc;
             pst.resize(2 * (size_t)P);
             pobj.resize(2 * (size_t)P);
-            xrow.resize(P);
             HIP_TRY(ctx, hipStreamSynchronize(st));
             HIP_TRY(ctx, hipMemcpy(pst.data(), t->pp_status, pst.size() * 4, hipMemcpyDeviceToHost));
             HIP_TRY(ctx, hipMemcpy(pobj.data(), t->pp_obj, pobj.size() * 8, hipMemcpyDeviceToHost));
-            {   // values of the probed variables: one bulk read of the batch's x
-                std::vector<double> xall((size_t)B * n);
-                HIP_TRY(ctx, hipMemcpy(xall.data(), t->d_x, xall.size() * 8, hipMemcpyDeviceToHost));
-                for (int e = 0; e < P; e++) xrow[e] = xall[(size_t)pair_pos[e] * n + pair_var[e]];
-            }
             t->probes += 2 * P;
         }
         // table updates in the reference's order: node by node; per node its probes (ascending
