@@ -166,9 +166,9 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
                 for (int h = m2 / 2; h >= 1; h >>= 1) part = part + __shfl_down(part, h, 64);
             } else {
                 // lane holds elements lane + 64*k: fold the k levels in registers, then across lanes
-                double e[8];
-                const int per = m2 / 64;  // <= 8 for m <= 512
-                for (int k = 0; k < 8; k++) {
+                double e[16];
+                const int per = m2 / 64;  // <= 16 for m <= 1024
+                for (int k = 0; k < 16; k++) {
                     const int j = lane + 64 * k;
                     e[k] = (k < per && j < m) ? ps[j] * g.b[j] : 0.0;
                 }

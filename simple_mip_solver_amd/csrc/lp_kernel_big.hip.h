@@ -1,0 +1,397 @@
+// lp_kernel_big.hip.h -- K1b: the same canonical dual simplex as K1 for node LPs whose tableau
+// does not fit the register file of one CU (above 256 x 192; BASELINE config C5 is 1024 x 512 =
+// 4 MiB of tableau).  One workgroup of 1024 threads per LP; the tableau lives in a per-workgroup
+// HBM scratch slab and is STREAMED once per pivot (one coalesced read + one write of every row):
+// this is the regime SURVEY.md section 8(d) prices, 2*8*(m+1)(n+m+1) bytes per pivot, and the
+// kernel is bound by HBM bandwidth.  Borders and the pivot row/column live in LDS (dynamic,
+// ~100 KiB at 1024 x 512).  Same arithmetic, same selections, same reductions as K1, so results
+// are bit-identical to the oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lp_kernel.hip.h"
+
+namespace mipx {
+
+constexpr int kBigNT = 1024;
+constexpr int kBigMaxN = 1024;  // 16 elements per lane in the wave folds
+constexpr int kBigMaxM = 1024;
+
+__host__ __device__ inline size_t big_lds_bytes(int m, int n) {
+    const size_t dbl = (size_t)n * 10 + (size_t)m * 4 + 8;   // row d va vb lo up key aabs dje x | alpha beta0 ba bb | cd
+    const size_t i32 = (size_t)n * 3 + (size_t)m + 8;        // nvar side wlist | bvar | nw ci
+    const size_t i8 = 2 * (size_t)(n + m);
+    return dbl * 8 + i32 * 4 + i8 + 64;
+}
+
+__global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *scratch) {
+    constexpr int NT = kBigNT, NW = NT / 64, CT = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = g.m, n = g.n, nv = n + m;
+    const double INF = __builtin_huge_val();
+    int n2 = 64;
+    while (n2 < n) n2 <<= 1;
+    const int PER = n2 / 64;            // <= 16
+    const int PIr = (m + 63) / 64;      // rows per lane in a wave scan
+    // ---- LDS carve ----------------------------------------------------------------------------
+    double *s_row = (double *)smem_raw;
+    double *s_d = s_row + n, *s_va = s_d + n, *s_vb = s_va + n, *s_lo = s_vb + n, *s_up = s_lo + n;
+    double *s_key = s_up + n, *s_aabs = s_key + n, *s_dje = s_aabs + n, *s_x = s_dje + n;
+    double *s_alpha = s_x + n, *s_beta0 = s_alpha + m, *s_ba = s_beta0 + m, *s_bb = s_ba + m;
+    double *s_cd = s_bb + m;
+    int *s_nvar = (int *)(s_cd + 8), *s_side = s_nvar + n, *s_wlist = s_side + n, *s_bvar = s_wlist + n;
+    int *s_ci = s_bvar + m;             // [0..3] control words, [4] nw
+    int8_t *s_wantb = (int8_t *)(s_ci + 8), *s_atup = s_wantb + nv;
+    double *T = scratch + (size_t)blockIdx.x * (size_t)m * n;
+
+    for (int node = blockIdx.x; node < g.batch; node += gridDim.x) {
+        const size_t src = g.slot ? (size_t)g.slot[node] : (size_t)node;
+        const double *gA = g.A + (size_t)node * g.A_stride;
+        const double *gb = g.b + (size_t)node * g.b_stride;
+        const double *gc = g.c + (size_t)node * g.c_stride;
+        const double *lk = g.l + src * n, *uk = g.u + src * n;
+        const int8_t *vin = g.vstat_in ? g.vstat_in + src * nv : nullptr;
+        // ---- 0. T = -A, beta0 = -b, d = c, slack basis --------------------------------------
+        for (size_t e = tid; e < (size_t)m * n; e += NT) T[e] = -gA[e];
+        for (int i = tid; i < m; i += NT) { s_beta0[i] = -gb[i]; s_bvar[i] = n + i; s_ba[i] = 0.0; s_bb[i] = 0.0; }
+        for (int j = tid; j < n; j += NT) {
+            s_d[j] = gc[j]; s_nvar[j] = j; s_lo[j] = lk[j]; s_up[j] = uk[j];
+            s_side[j] = 0; s_va[j] = 0.0; s_vb[j] = 0.0;
+        }
+        for (int v = tid; v < nv; v += NT) {
+            const int8_t st = vin ? vin[v] : (int8_t)0;
+            s_wantb[v] = st == 1; s_atup[v] = st == 2;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int cnt = 0;
+            for (int base = 0; base < n; base += 64) {
+                const int j = base + lane;
+                const bool w = j < n && s_wantb[j];
+                const unsigned long long mask = __ballot(w);
+                if (w) s_wlist[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+                cnt += __popcll(mask);
+            }
+            if (lane == 0) s_ci[4] = cnt;
+        }
+        __syncthreads();
+        const int nw = __builtin_amdgcn_readfirstlane(s_ci[4]);
+        int npiv = 0, iters = 0, status = -1, phase = vin ? 0 : 1, w = 0, degen = 0;
+        const int cap = 100 * (m + n) + 1000;
+        const bool ctl = tid < CT;
+
+        for (;;) {
+            int r = 0, q = 0, sigma = 1, newside = 0;
+            double la = 0.0, lb = 0.0, pinv = 0.0;
+            if (phase == 0) {
+                if (w >= nw) { phase = 1; continue; }
+                q = __builtin_amdgcn_readfirstlane(s_wlist[w]);
+                w++;
+                for (int i = tid; i < m; i += NT) s_alpha[i] = T[(size_t)i * n + q];
+                __syncthreads();
+                if (ctl) {
+                    double k1 = -INF, k2 = -INF;
+                    int p1 = kNoCand, p2 = kNoCand;
+#pragma unroll 1
+                    for (int kk = 0; kk < PIr; kk++) {
+                        const int i = lane + 64 * kk;
+                        if (i < m) {
+                            const int bv = s_bvar[i];
+                            const double a = fabs(s_alpha[i]);
+                            const bool ok = bv >= n && a > kPivTol;
+                            keep(k2, p2, a, i, ok);
+                            keep(k1, p1, a, i, ok && !s_wantb[bv >= n ? bv : n]);
+                        }
+                    }
+                    double km;
+                    int rr = wave_argmax(k1, p1, km);
+                    if (rr == kNoCand) rr = wave_argmax(k2, p2, km);
+                    if (tid == 0) {
+                        s_ci[0] = rr == kNoCand ? -1 : rr;
+                        if (rr != kNoCand) s_cd[0] = 1.0 / s_alpha[rr];
+                    }
+                }
+                __syncthreads();
+                r = __builtin_amdgcn_readfirstlane(s_ci[0]);
+                if (r < 0) continue;
+                pinv = s_cd[0];
+                for (int j = tid; j < n; j += NT) s_row[j] = T[(size_t)r * n + j];
+            } else if (phase == 1) {
+                for (int j = tid; j < n; j += NT) {
+                    const int v = s_nvar[j];
+                    const double lo = v < n ? s_lo[v] : 0.0, up = v < n ? s_up[v] : INF;
+                    const double dj = s_d[j];
+                    int side;
+                    if (lo == up) side = 0;
+                    else if (dj < -kDTol) side = isinf(up) ? 2 : 1;
+                    else if (dj > kDTol) side = 0;
+                    else side = (s_atup[v] && !isinf(up)) ? 1 : 0;
+                    s_side[j] = side;
+                    s_va[j] = side == 0 ? lo : side == 1 ? up : 0.0;
+                    s_vb[j] = side == 2 ? 1.0 : 0.0;
+                }
+                __syncthreads();
+                // beta = beta0 - T v  (fold-in-half tree over n2; lane holds j = lane + 64 k)
+                for (int i = wave; i < m; i += NW) {
+                    const double *Ti = T + (size_t)i * n;
+                    double pa[16], pb[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const int j = lane + 64 * k;
+                        const double t = (k < PER && j < n) ? Ti[j] : 0.0;
+                        pa[k] = (k < PER && j < n) ? t * s_va[j] : 0.0;
+                        pb[k] = (k < PER && j < n) ? t * s_vb[j] : 0.0;
+                    }
+                    for (int h = PER / 2; h >= 1; h >>= 1) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                            if (k < h) { pa[k] = pa[k] + pa[k + h]; pb[k] = pb[k] + pb[k + h]; }
+                    }
+                    double sa = pa[0], sb = pb[0];
+#pragma unroll
+                    for (int h = 32; h >= 1; h >>= 1) {
+                        sa = sa + __shfl_down(sa, h, 64);
+                        sb = sb + __shfl_down(sb, h, 64);
+                    }
+                    if (lane == 0) { s_ba[i] = s_beta0[i] - sa; s_bb[i] = 0.0 - sb; }
+                }
+                __syncthreads();
+                phase = 2;
+                continue;
+            } else {
+                const bool bland = degen > m + n;
+                if (ctl) {
+                    int blevel = 0, bp = kNoCand;
+                    double bk = -INF;
+#pragma unroll 1
+                    for (int kk = 0; kk < PIr; kk++) {
+                        const int i = lane + 64 * kk;
+                        if (i < m) {
+                            const int v = s_bvar[i];
+                            const double lo = v < n ? s_lo[v] : 0.0, up = v < n ? s_up[v] : INF;
+                            const double a = s_ba[i], bM = s_bb[i];
+                            int level = 0, sg = 0;
+                            double viol = 0.0;
+                            if (bM < -kBTol) { level = 2; viol = -bM; sg = 1; }
+                            else if (bM > kBTol) {
+                                if (!isinf(up)) { level = 2; viol = bM; sg = -1; }
+                                else if (bM > 1.0 + kBTol) { level = 2; viol = bM - 1.0; sg = -1; }
+                                else if (bM >= 1.0 - kBTol && a > kPTol) { level = 1; viol = a; sg = -1; }
+                            } else {
+                                if (a < lo - kPTol) { level = 1; viol = lo - a; sg = 1; }
+                                else if (!isinf(up) && a > up + kPTol) { level = 1; viol = a - up; sg = -1; }
+                            }
+                            if (bland && level > 0) { level = 1; viol = 0.0; }
+                            const int pay = (v << 16) | (sg < 0 ? 0x8000 : 0) | i;
+                            const bool up_lvl = level > blevel;
+                            const bool same = level == blevel && level > 0 &&
+                                              (viol > bk || (viol == bk && pay < bp));
+                            if (up_lvl || same) { blevel = level; bk = viol; bp = pay; }
+                        }
+                    }
+                    const int lvl = wave_max_i32(blevel);
+                    int cmd = 0, win = 0;
+                    if (lvl == 0) {
+                        int bad = 0;
+                        for (int i = lane; i < m; i += 64) bad |= s_bb[i] > kBTol;
+                        for (int j = lane; j < n; j += 64) bad |= s_side[j] == 2;
+                        cmd = __any(bad) ? 3 : 1;
+                    } else if ((g.max_iter > 0 && iters >= g.max_iter) || iters >= cap) {
+                        cmd = 4;
+                    } else {
+                        double km;
+                        win = wave_argmax(blevel == lvl ? bk : -INF, blevel == lvl ? bp : kNoCand, km);
+                    }
+                    if (tid == 0) { s_ci[0] = cmd; s_ci[1] = win; }
+                }
+                __syncthreads();
+                {
+                    const int cmd = __builtin_amdgcn_readfirstlane(s_ci[0]);
+                    if (cmd) { status = cmd == 1 ? 0 : cmd == 3 ? 2 : 3; break; }
+                    const int win = __builtin_amdgcn_readfirstlane(s_ci[1]);
+                    r = win & 0x7fff;
+                    sigma = (win & 0x8000) ? -1 : 1;
+                }
+                for (int j = tid; j < n; j += NT) s_row[j] = T[(size_t)r * n + j];
+                __syncthreads();
+                if (ctl) {
+#pragma unroll 1
+                    for (int j = tid; j < n; j += CT) {
+                        const int v = s_nvar[j];
+                        const double lo = v < n ? s_lo[v] : 0.0, up = v < n ? s_up[v] : INF;
+                        const double a = sigma * s_row[j];
+                        const int sd = s_side[j];
+                        const bool elig = lo != up && (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
+                        const double dj = sd == 0 ? fmax(s_d[j], 0.0) : fmax(-s_d[j], 0.0);
+                        const double aa = fabs(a);
+                        s_key[j] = elig ? (bland ? dj / aa : (dj + kDTol) / aa) : INF;
+                        s_aabs[j] = elig ? aa : -1.0;
+                        s_dje[j] = dj;
+                    }
+                }
+                __syncthreads();
+                if (ctl) {
+                    double k1 = -INF;
+                    int p1 = kNoCand;
+#pragma unroll 1
+                    for (int kk = 0; kk < PER; kk++) {
+                        const int j = lane + 64 * kk;
+                        if (j < n) keep(k1, p1, -s_key[j], (s_nvar[j] << 16) | j, s_aabs[j] >= 0.0);
+                    }
+                    double nthmax;
+                    const int w1 = wave_argmax(k1, p1, nthmax);
+                    int qq = -1;
+                    if (w1 != kNoCand && bland) {
+                        qq = w1 & 0xffff;
+                    } else if (w1 != kNoCand) {
+                        const double thmax = -nthmax;
+                        const int jmin = w1 & 0xffff;
+                        double k2 = -INF;
+                        int p2 = kNoCand;
+#pragma unroll 1
+                        for (int kk = 0; kk < PER; kk++) {
+                            const int j = lane + 64 * kk;
+                            if (j < n) {
+                                const double aa = s_aabs[j];
+                                const bool ok = aa >= 0.0 && (j == jmin || !(s_dje[j] > thmax * aa));
+                                keep(k2, p2, aa, (s_nvar[j] << 16) | j, ok);
+                            }
+                        }
+                        double amax;
+                        qq = wave_argmax(k2, p2, amax) & 0xffff;
+                    }
+                    if (qq >= 0) degen = s_dje[qq] <= kDTol ? degen + 1 : 0;
+                    if (tid == 0) {
+                        s_ci[0] = qq;
+                        if (qq >= 0) s_cd[0] = 1.0 / s_row[qq];
+                    }
+                }
+                __syncthreads();
+                q = __builtin_amdgcn_readfirstlane(s_ci[0]);
+                if (q < 0) { status = 1; break; }
+                pinv = s_cd[0];
+                for (int i = tid; i < m; i += NT) s_alpha[i] = T[(size_t)i * n + q];
+                const int lv = s_bvar[r];
+                const double lo = lv < n ? s_lo[lv] : 0.0, up = lv < n ? s_up[lv] : INF;
+                if (sigma > 0) { la = lo; lb = 0.0; newside = 0; }
+                else if (!isinf(up)) { la = up; lb = 0.0; newside = 1; }
+                else { la = 0.0; lb = 1.0; newside = 2; }
+            }
+            const double dq = s_d[q], b0r = s_beta0[r];
+            const double bar = s_ba[r], bbr = s_bb[r], vaq = s_va[q], vbq = s_vb[q];
+            __syncthreads();
+            {   // ---- stream the tableau: T_ij <- fma(-alpha_i, rho_j, T_ij) ---------------------
+                const bool vals = phase == 2;
+                double rj[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int j = lane + 64 * k;
+                    rj[k] = (k < PER && j < n) ? s_row[j] * pinv : 0.0;
+                }
+                for (int i = wave; i < m; i += NW) {
+                    double *Ti = T + (size_t)i * n;
+                    const double a = s_alpha[i];
+                    if (i == r) {
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const int j = lane + 64 * k;
+                            if (k < PER && j < n) Ti[j] = j == q ? pinv : rj[k];
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const int j = lane + 64 * k;
+                            if (k < PER && j < n) Ti[j] = j == q ? -a * pinv : fma(-a, rj[k], Ti[j]);
+                        }
+                    }
+                }
+                const double rhon = b0r * pinv;
+                const double ta = (bar - la) * pinv, tb = (bbr - lb) * pinv;
+                for (int i = tid; i < m; i += NT) {
+                    const double a = s_alpha[i];
+                    if (i == r) {
+                        s_beta0[i] = rhon;
+                        if (vals) { s_ba[i] = vaq + ta; s_bb[i] = vbq + tb; }
+                    } else {
+                        s_beta0[i] = fma(-a, rhon, s_beta0[i]);
+                        if (vals) { s_ba[i] = fma(-a, ta, s_ba[i]); s_bb[i] = fma(-a, tb, s_bb[i]); }
+                    }
+                }
+                for (int j = tid; j < n; j += NT) {
+                    if (j == q) {
+                        s_d[j] = -dq * pinv;
+                        if (vals) { s_side[j] = newside; s_va[j] = la; s_vb[j] = lb; }
+                    } else {
+                        s_d[j] = fma(-dq, s_row[j] * pinv, s_d[j]);
+                    }
+                }
+                if (tid == NT - 1) { const int tmp = s_bvar[r]; s_bvar[r] = s_nvar[q]; s_nvar[q] = tmp; }
+            }
+            __syncthreads();
+            npiv++;
+            if (phase == 2) iters++;
+        }
+
+        // ---- outputs -----------------------------------------------------------------------------
+        for (int j = tid; j < n; j += NT) {
+            const int v = s_nvar[j];
+            if (v < n) s_x[v] = s_side[j] == 2 ? kMReport : s_va[j];
+        }
+        for (int i = tid; i < m; i += NT) {
+            const int v = s_bvar[i];
+            if (v < n) s_x[v] = fma(s_bb[i], kMReport, s_ba[i]);
+        }
+        __syncthreads();
+        if (g.x) for (int j = tid; j < n; j += NT) g.x[(size_t)node * n + j] = s_x[j];
+        if (g.y) {
+            for (int i = tid; i < m; i += NT) g.y[(size_t)node * m + i] = 0.0;
+            __syncthreads();
+            for (int j = tid; j < n; j += NT)
+                if (s_nvar[j] >= n) g.y[(size_t)node * m + (s_nvar[j] - n)] = s_d[j];
+        }
+        if (g.vstat_out) {
+            int8_t *vo = g.vstat_out + (size_t)node * nv;
+            for (int i = tid; i < m; i += NT) vo[s_bvar[i]] = 1;
+            for (int j = tid; j < n; j += NT) vo[s_nvar[j]] = s_side[j] ? 2 : 3;
+        }
+        if (g.dbg_T && (node == 0 || g.dbg_all)) {
+            const size_t k = g.dbg_all ? (size_t)node : 0;
+            double *dT = g.dbg_T + k * (size_t)m * n;
+            double *dvec = g.dbg_vec + k * (size_t)(n + 3 * m);
+            int32_t *didx = g.dbg_idx + k * (size_t)(2 * n + m);
+            for (size_t e = tid; e < (size_t)m * n; e += NT) dT[e] = T[e];
+            for (int j = tid; j < n; j += NT) { dvec[j] = s_d[j]; didx[j] = s_nvar[j]; didx[n + m + j] = s_side[j]; }
+            for (int i = tid; i < m; i += NT) {
+                dvec[n + i] = s_beta0[i]; dvec[n + m + i] = s_ba[i]; dvec[n + 2 * m + i] = s_bb[i];
+                didx[n + i] = s_bvar[i];
+            }
+        }
+        if (tid < 64) {
+            double p[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int j = lane + 64 * k;
+                p[k] = (k < PER && j < n) ? gc[j] * s_x[j] : 0.0;
+            }
+            for (int h = PER / 2; h >= 1; h >>= 1) {
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (k < h) p[k] = p[k] + p[k + h];
+            }
+            double sum = p[0];
+#pragma unroll
+            for (int h = 32; h >= 1; h >>= 1) sum = sum + __shfl_down(sum, h, 64);
+            if (tid == 0) {
+                if (g.obj) g.obj[node] = status == 1 ? INF : sum;
+                if (g.status) g.status[node] = status;
+                if (g.iters) g.iters[node] = iters;
+                if (g.npivots) g.npivots[node] = npiv;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace mipx

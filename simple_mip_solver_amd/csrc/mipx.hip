@@ -11,6 +11,7 @@
 
 #include "../../include/mipx.h"
 #include "lp_kernel.hip.h"
+#include "lp_kernel_big.hip.h"
 
 struct mipx_ctx {
     int device = -1;
@@ -29,6 +30,9 @@ struct mipx_problem {
     // debug dump buffers (device), enabled by mipx_debug_enable
     double *dbg_T = nullptr, *dbg_vec = nullptr;
     int32_t *dbg_idx = nullptr;
+    // K1b (tableau streamed from HBM): one m x n slab per concurrently resident workgroup
+    double *big_scratch = nullptr;
+    int big_slabs = 0;
 };
 
 namespace {
@@ -76,6 +80,35 @@ const KernelCfg *pick_cfg(int m, int n) {
 }
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+bool big_fits(int m, int n) { return m >= 1 && m <= mipx::kBigMaxM && n <= mipx::kBigMaxN; }
+bool shape_supported(int m, int n) { return pick_cfg(m, n) != nullptr || big_fits(m, n); }
+
+// Launch K1 (register-resident tableau) or, above its tiles, K1b (tableau streamed from HBM).
+int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch) {
+    mipx_ctx *ctx = p->ctx;
+    if (const KernelCfg *cfg = pick_cfg(p->m, p->n)) {
+        cfg->launch(a, batch, ctx->stream);
+        HIP_TRY(ctx, hipGetLastError());
+        return MIPX_OK;
+    }
+    if (!big_fits(p->m, p->n)) return fail(ctx, MIPX_ETOOBIG, "(m,n) exceeds every LP kernel");
+    const int slabs = batch < 1024 ? batch : 1024;  // 1024 x 4 MiB = 4 GiB at 1024 x 512
+    if (slabs > p->big_slabs) {
+        if (p->big_scratch) (void)hipFree(p->big_scratch);
+        p->big_scratch = nullptr;
+        p->big_slabs = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&p->big_scratch, (size_t)slabs * p->m * p->n * sizeof(double)));
+        p->big_slabs = slabs;
+    }
+    const size_t lds = mipx::big_lds_bytes(p->m, p->n);
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)mipx::lp_dual_simplex_big,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mipx::lp_dual_simplex_big, dim3(slabs), dim3(mipx::kBigNT), lds, ctx->stream,
+                       a, p->big_scratch);
+    HIP_TRY(ctx, hipGetLastError());
+    return MIPX_OK;
+}
 
 }  // namespace
 
@@ -134,7 +167,7 @@ int mipx_problem_create(mipx_ctx *ctx, int m, int n, const double *A, const doub
     if (!ctx || !out || m < 0 || n <= 0 || !c || (m > 0 && (!A || !b)))
         return fail(ctx, MIPX_EINVAL, "mipx_problem_create: bad argument");
     *out = nullptr;
-    if (!pick_cfg(m, n)) return fail(ctx, MIPX_ETOOBIG, "mipx_problem_create: (m,n) exceeds on-chip tableau kernels");
+    if (!shape_supported(m, n)) return fail(ctx, MIPX_ETOOBIG, "mipx_problem_create: (m,n) exceeds every LP kernel");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     mipx_problem *p = new (std::nothrow) mipx_problem();
     if (!p) return fail(ctx, MIPX_ENOMEM, "mipx_problem_create: host alloc");
@@ -169,6 +202,7 @@ void mipx_problem_destroy(mipx_problem *p) {
     if (p->dbg_T) (void)hipFree(p->dbg_T);
     if (p->dbg_vec) (void)hipFree(p->dbg_vec);
     if (p->dbg_idx) (void)hipFree(p->dbg_idx);
+    if (p->big_scratch) (void)hipFree(p->big_scratch);
     delete p;
 }
 
@@ -180,8 +214,6 @@ int mipx_lp_solve_batch_dev(mipx_problem *p, int batch, const double *l, const d
     mipx_ctx *ctx = p->ctx;
     if (batch < 0 || (batch > 0 && (!l || !u))) return fail(ctx, MIPX_EINVAL, "mipx_lp_solve_batch_dev: bad argument");
     if (batch == 0) return MIPX_OK;
-    const KernelCfg *cfg = pick_cfg(p->m, p->n);
-    if (!cfg) return fail(ctx, MIPX_ETOOBIG, "mipx_lp_solve_batch_dev: (m,n) too big");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     mipx::LpArgs a;
     a.m = p->m; a.n = p->n;
@@ -191,9 +223,7 @@ int mipx_lp_solve_batch_dev(mipx_problem *p, int batch, const double *l, const d
     a.status = status; a.obj = obj; a.x = x; a.y = y; a.vstat_out = vstat_out;
     a.iters = iters; a.npivots = npivots; a.batch = batch;
     a.dbg_T = p->dbg_T; a.dbg_vec = p->dbg_vec; a.dbg_idx = p->dbg_idx; a.dbg_all = 0;
-    cfg->launch(a, batch, ctx->stream);
-    HIP_TRY(ctx, hipGetLastError());
-    return MIPX_OK;
+    return launch_lp_any(p, a, batch);
 }
 
 int mipx_lp_solve_batch(mipx_problem *p, int batch, const double *l, const double *u,
@@ -327,8 +357,6 @@ int mipx_gomory_batch(mipx_problem *p, int batch, const double *l, const double 
     if (batch < 0 || (batch && (!l || !u || !vstat || !x || !is_int || !ncuts)))
         return fail(ctx, MIPX_EINVAL, "mipx_gomory_batch: bad argument");
     if (batch == 0) return MIPX_OK;
-    const KernelCfg *cfg = pick_cfg(p->m, p->n);
-    if (!cfg) return fail(ctx, MIPX_ETOOBIG, "mipx_gomory_batch: (m,n) too big");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t B = (size_t)batch, n = (size_t)p->n, m = (size_t)(p->m ? p->m : 1), nv = n + p->m;
     size_t off = 0;
@@ -360,7 +388,9 @@ int mipx_gomory_batch(mipx_problem *p, int batch, const double *l, const double 
         a.iters = nullptr; a.npivots = nullptr; a.batch = batch;
         a.dbg_T = (double *)(base + o_T); a.dbg_vec = (double *)(base + o_vec);
         a.dbg_idx = (int32_t *)(base + o_idx); a.dbg_all = 1;
-        cfg->launch(a, batch, st);
+        rc = launch_lp_any(p, a, batch);
+    }
+    if (rc == MIPX_OK) {
         mipx::GomoryArgs g;
         g.m = p->m; g.n = p->n; g.batch = batch;
         g.A = p->dA; g.b = p->db;
@@ -483,9 +513,9 @@ int mipx_timer_stop(mipx_ctx *ctx, float *ms) {
 
 int mipx_kernel_name(int m, int n, char *buf, size_t buflen) {
     const KernelCfg *cfg = pick_cfg(m, n);
-    if (!cfg) return MIPX_ETOOBIG;
+    if (!cfg && !big_fits(m, n)) return MIPX_ETOOBIG;
     if (!buf || buflen == 0) return MIPX_EINVAL;
-    std::snprintf(buf, buflen, "%s", cfg->name);
+    std::snprintf(buf, buflen, "%s", cfg ? cfg->name : "lp_dual_simplex_big");
     return MIPX_OK;
 }
 

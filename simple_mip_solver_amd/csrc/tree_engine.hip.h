@@ -153,8 +153,6 @@ void tree_push(mipx_tree *t, int64_t id) {
 int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const int8_t *v,
               const int32_t *slot, int max_iter, int32_t *status, double *obj, double *x,
               int8_t *vout, int32_t *iters, int32_t *npiv) {
-    mipx_ctx *ctx = t->ctx;
-    const KernelCfg *cfg = pick_cfg(t->m, t->n);
     mipx::LpArgs a;
     a.m = t->m; a.n = t->n;
     a.A = t->prob->dA; a.b = t->prob->db; a.c = t->prob->dc;
@@ -163,9 +161,7 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
     a.status = status; a.obj = obj; a.x = x; a.y = nullptr; a.vstat_out = vout;
     a.iters = iters; a.npivots = npiv; a.batch = batch;
     a.dbg_T = nullptr; a.dbg_vec = nullptr; a.dbg_idx = nullptr; a.dbg_all = 0;
-    cfg->launch(a, batch, ctx->stream);
-    HIP_TRY(ctx, hipGetLastError());
-    return MIPX_OK;
+    return launch_lp_any(t->prob, a, batch);
 }
 
 int launch_score(mipx_tree *t, int batch) {

@@ -124,9 +124,40 @@ def test_with_extra_rows_uses_tall_kernel(gpu_ctx, oracle):
 
 
 def test_too_big_fails_loudly(gpu_ctx):
-    A, b, c, l, u, _ = random_dense_milp_arrays(1024, 512, seed=0)
+    A, b, c, l, u, _ = random_dense_milp_arrays(1100, 20, seed=0)
     with pytest.raises(_ffi.MipxError, match='MIPX_ETOOBIG'):
         _ffi.Problem(gpu_ctx, A, b, c)
+
+
+@pytest.mark.parametrize('n,m,seed', [(300, 150, 0), (512, 256, 1)])
+def test_hbm_streaming_kernel_full_solves(n, m, seed, gpu_ctx, oracle):
+    """K1b (tableau streamed from HBM) above the register tiles: cold root to optimality, then
+    warm-started children and 5-iteration probes, bit-exact against the oracle."""
+    assert _ffi.kernel_name(m, n) == 'lp_dual_simplex_big'
+    A, b, c, l, u, _ = random_dense_milp_arrays(n, m, seed=seed)
+    p = _ffi.Problem(gpu_ctx, A, b, c)
+    root = p.solve_batch(l[None], u[None])
+    assert_same(root, oracle.lp_solve_batch(A, b, c, l[None], u[None]), 'root')
+    assert root['status'][0] == 0
+    L, U, V = _children(A, b, c, l, u, root, 6)
+    assert_same(p.solve_batch(L, U, V), oracle.lp_solve_batch(A, b, c, L, U, V), 'children')
+    assert_same(p.solve_batch(L, U, V, max_iter=5), oracle.lp_solve_batch(A, b, c, L, U, V, max_iter=5), 'probes')
+
+
+def test_s5_shape_1024x512(gpu_ctx, oracle):
+    """BASELINE config C5 shape: 1024 vars x 512 rows.  The cold root needs tens of thousands of
+    pivots, so parity is checked on truncated solves (every state after k pivots must agree) and on
+    a warm start from the truncated basis."""
+    A, b, c, l, u, _ = random_dense_milp_arrays(1024, 512, seed=0)
+    p = _ffi.Problem(gpu_ctx, A, b, c)
+    for k in (1, 7, 200):
+        assert_same(p.solve_batch(l[None], u[None], max_iter=k),
+                    oracle.lp_solve_batch(A, b, c, l[None], u[None], max_iter=k), f'{k} pivots')
+    g = p.solve_batch(l[None], u[None], max_iter=200)
+    assert g['status'][0] == 3 and g['iters'][0] == 200
+    warm = p.solve_batch(l[None], u[None], g['vstat'], max_iter=50)   # refactor + 50 more pivots
+    assert_same(warm, oracle.lp_solve_batch(A, b, c, l[None], u[None], g['vstat'], max_iter=50), 'warm')
+    assert warm['npivots'][0] > 50 and warm['obj'][0] >= g['obj'][0] - 1e-6
 
 
 def test_warm_start_with_padding_after_lds_pollution(gpu_ctx, oracle):
