@@ -161,3 +161,39 @@ def test_native_mode_argument_checks():
         pass
     with pytest.raises(AssertionError, match='only available for the stock node classes'):
         BranchAndBound(m, Node=Mine, gomory_cuts=False, frontier_batch=4)
+
+
+def test_keep_shard_partitions_the_open_nodes(gpu_ctx=None):
+    """Multi-GPU sharding, simulated in one process: two engines run the same deterministic
+    ramp-up, each keeps its share; the shares are disjoint, cover the frontier, and the MIN of the
+    shard dual bounds is the dual bound of the whole tree."""
+    from simple_mip_solver_amd import _ffi
+    ctx = _ffi.default_context()
+    A, b, c, l, u, ints = random_dense_milp_arrays(40, 16, seed=3)
+    prob = _ffi.Problem(ctx, A, b, c)
+
+    def ramp():
+        t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=8, pool_capacity=4096)
+        st = t.stats()
+        while st['open_nodes'] < 24:
+            st = t.solve(mip_gap=0.0, frontier_batch=8, max_steps=1)
+            assert st['status'] == 4
+        return t, st
+    whole, st_all = ramp()
+    L_all, U_all, V_all, db_all = whole.peek_open(10 ** 6)
+    shards = []
+    for rank in range(2):
+        t, st = ramp()
+        assert st['open_nodes'] == st_all['open_nodes'] and st['dual_bound'] == st_all['dual_bound']
+        t.keep_shard(rank, 2)
+        shards.append(t)
+    parts = [s.peek_open(10 ** 6) for s in shards]
+    assert len(parts[0][0]) + len(parts[1][0]) == len(L_all)
+    assert abs(len(parts[0][0]) - len(parts[1][0])) <= 1
+    keys = lambda P: sorted(map(lambda k: (P[0][k].tobytes(), P[1][k].tobytes()), range(len(P[0]))))
+    assert sorted(keys(parts[0]) + keys(parts[1])) == keys((L_all, U_all))
+    assert min(s.stats()['dual_bound'] for s in shards) == st_all['dual_bound']
+    # every shard can keep searching on its own and never beats the whole tree's bound
+    for s in shards:
+        st = s.solve(mip_gap=0.0, frontier_batch=8, max_steps=3)
+        assert st['dual_bound'] >= st_all['dual_bound'] - 1e-9
