@@ -53,6 +53,8 @@ def main():
     ap.add_argument('--cons', type=int, default=128)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-anchor', action='store_true',
+                    help='refactor every node from the slack basis instead of the root tableau')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -74,6 +76,9 @@ def main():
     tree = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', search_rule='best first',
                      strong_branch_iters=5, max_batch=B,
                      pool_capacity=2 * B * (args.steps + args.warmup + 4) + 4 * B * world)
+
+    if not args.no_anchor:
+        tree.set_anchor_mode(True)  # warm starts refactor from the root's optimal tableau
 
     # ---- untimed: replicated ramp-up, then sharding ------------------------------------------
     st = tree.stats()
@@ -177,6 +182,7 @@ def main():
                             f'{args.seed}), PseudoCostBranchNode, best-first, strong_branch_iters=5, '
                             f'gomory_cuts=False, native frontier engine, {B} open nodes per step per GPU',
                 'frontier_batch_per_gpu': B, 'kernel': _ffi.kernel_name(m, n),
+                'anchored_refactorisation': not args.no_anchor,
                 'mean_pivots_per_lp': d['pivots'] / max(1, d['lp_solved']),
                 'sb_probes_per_s': sums[1] / elapsed,
                 'nodes_evaluated_total': sums[4], 'open_nodes_total': sums[3],

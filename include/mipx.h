@@ -62,6 +62,14 @@ int mipx_ctx_sync(mipx_ctx *ctx);
 int mipx_problem_create(mipx_ctx *ctx, int m, int n, const double *A_rowmajor, const double *b,
                         const double *c, mipx_problem **out);
 void mipx_problem_destroy(mipx_problem *p);
+/*
+ * Optional: make warm starts refactor from the tableau of the basis `vstat` (n+m Clp codes, e.g.
+ * the root's optimal basis) instead of from the slack basis.  The number of refactorisation pivots
+ * of a node then equals the distance between its basis and the anchor's, not the number of its
+ * basic structurals.  NULL switches it off.  Results stay within rounding of the unanchored solve
+ * (a different, equally valid pivot sequence); only the register-resident tiles support it.
+ */
+int mipx_problem_set_anchor(mipx_problem *p, const int8_t *vstat);
 
 /*
  * Batched node LP relaxation: replaces `self.lp.dual()` + the status/objective/solution reads
@@ -207,6 +215,8 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
 int mipx_tree_get_stats(mipx_tree *t, mipx_tree_stats *out);
 int mipx_tree_solution(mipx_tree *t, double *x);
 int mipx_tree_set_primal_bound(mipx_tree *t, double bound); /* initial_primal_bound / exchange */
+/* Throughput option: once the root is solved, anchor every later refactorisation at its tableau. */
+int mipx_tree_set_anchor_mode(mipx_tree *t, int on);
 int mipx_tree_pseudo_costs(mipx_tree *t, double *cost_l, double *cost_r, int32_t *times_l,
                            int32_t *times_r);
 /* Copy the records of up to max_nodes open nodes (queue-array order) to HOST buffers without

@@ -67,6 +67,17 @@ void mipx_oracle_set_dump(double *T, double *vec, int32_t *idx) {
     g_dump_T = T; g_dump_vec = vec; g_dump_idx = idx;
 }
 
+/* optional anchor: a tableau state (T, d, beta0, nvar, bvar -- the layout of the dump) of some
+ * basis of the same rows from which the warm-start refactorisation starts instead of the slack
+ * basis; set by tests through mipx_oracle_set_anchor, cleared with NULLs */
+static const double *g_anchor_T = 0, *g_anchor_vec = 0;
+static const int32_t *g_anchor_idx = 0;
+static int g_refactor_only = 0;
+void mipx_oracle_set_anchor(const double *T, const double *vec, const int32_t *idx) {
+    g_anchor_T = T; g_anchor_vec = vec; g_anchor_idx = idx;
+}
+void mipx_oracle_set_refactor_only(int on) { g_refactor_only = on; }
+
 static int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 /* fold-in-half summation tree over a power-of-two length buffer (destroys p) */
@@ -151,12 +162,18 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
     double *va = (double *)malloc(sizeof(double) * (size_t)n);
     double *vb = (double *)malloc(sizeof(double) * (size_t)n);
 
-    for (int i = 0; i < m; i++) {
-        for (int j = 0; j < n; j++) t.T[(size_t)i * n + j] = -A[(size_t)i * n + j];
-        t.beta0[i] = -b[i];
-        t.bvar[i] = n + i;
+    if (g_anchor_T && vstat_in) {
+        memcpy(t.T, g_anchor_T, sizeof(double) * (size_t)m * n);
+        for (int j = 0; j < n; j++) { t.d[j] = g_anchor_vec[j]; t.nvar[j] = g_anchor_idx[j]; }
+        for (int i = 0; i < m; i++) { t.beta0[i] = g_anchor_vec[n + i]; t.bvar[i] = g_anchor_idx[n + i]; }
+    } else {
+        for (int i = 0; i < m; i++) {
+            for (int j = 0; j < n; j++) t.T[(size_t)i * n + j] = -A[(size_t)i * n + j];
+            t.beta0[i] = -b[i];
+            t.bvar[i] = n + i;
+        }
+        for (int j = 0; j < n; j++) { t.d[j] = c[j]; t.nvar[j] = j; }
     }
-    for (int j = 0; j < n; j++) { t.d[j] = c[j]; t.nvar[j] = j; }
     int npiv = 0;
 
     /* 1. refactor to the warm-start basis */
@@ -165,27 +182,36 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
             wantb[v] = (vstat_in[v] == ST_BASIC);
             atup[v] = (vstat_in[v] == ST_UPPER);
         }
-        for (int q = 0; q < n; q++) {
-            if (!wantb[q]) continue;
+        /* every variable wanted basic that is nonbasic in the starting tableau enters, in
+         * ascending variable order; it replaces the basic variable of the row with the largest
+         * |T_iq| among rows whose variable is not wanted basic (fallback: wanted but not entered by
+         * this refactorisation); ties -> lowest row */
+        int *pos = (int *)malloc(sizeof(int) * (size_t)nv);
+        int8_t *entered = (int8_t *)calloc((size_t)(m + 1), 1);
+        for (int v = 0; v < nv; v++) pos[v] = -1;
+        for (int j = 0; j < n; j++) pos[t.nvar[j]] = j;
+        for (int v = 0; v < nv; v++) {
+            if (!wantb[v] || pos[v] < 0) continue;
+            const int q = pos[v];
             int best = -1; double bestv = MIPX_PIVTOL;
             for (int i = 0; i < m; i++) {
-                int bv = t.bvar[i];
-                if (bv < n || wantb[bv]) continue;
+                if (wantb[t.bvar[i]]) continue;
                 double a = fabs(t.T[(size_t)i * n + q]);
                 if (a > bestv) { bestv = a; best = i; }
             }
             if (best < 0) {
                 for (int i = 0; i < m; i++) {
-                    int bv = t.bvar[i];
-                    if (bv < n) continue;
+                    if (!wantb[t.bvar[i]] || entered[i]) continue;
                     double a = fabs(t.T[(size_t)i * n + q]);
                     if (a > bestv) { bestv = a; best = i; }
                 }
             }
             if (best < 0) continue; /* singular: stays nonbasic */
             tab_pivot(&t, best, q);
+            entered[best] = 1;
             npiv++;
         }
+        free(pos); free(entered);
     }
 
 #define VLO(v) ((v) < n ? l[(v)] : 0.0)
@@ -216,6 +242,7 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
 
     /* 3. dual simplex */
     int iters = 0, status = -1;
+    if (g_refactor_only) { status = 3; goto done; }
     int degen = 0; /* consecutive degenerate steps; > m+n switches to Bland's rule (anti-cycling) */
     const int cap = 100 * (m + n) + 1000;
     for (;;) {
@@ -313,6 +340,7 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
         }
     }
 
+done:
     if (g_dump_T) {
         memcpy(g_dump_T, t.T, sizeof(double) * (size_t)m * n);
         for (int j = 0; j < n; j++) {

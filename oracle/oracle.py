@@ -179,3 +179,30 @@ def select_cuts(pi, pi0, x, max_nonzero_coefs, min_cut_depth, cos_parallel, max_
                                       C.c_double(max_abs_coef), _p(added, _i32p), C.byref(term),
                                       _p(depth, _dp))
     return added[:k].copy(), int(term.value), depth[:K].copy()
+
+
+def make_anchor(A, b, c, vstat):
+    """Tableau state of basis `vstat` (refactorisation only), in the dump layout."""
+    A = np.ascontiguousarray(A, np.float64)
+    m, n = A.shape
+    lib().mipx_oracle_set_refactor_only(C.c_int(1))
+    try:
+        _, d = debug_dump(A, b, c, np.zeros(n), np.zeros(n), vstat, 0)
+    finally:
+        lib().mipx_oracle_set_refactor_only(C.c_int(0))
+    vec = np.ascontiguousarray(np.concatenate([d['d'], d['beta0'], d['ba'], d['bb']]))
+    idx = np.ascontiguousarray(np.concatenate([d['nvar'], d['bvar'], d['side']]), np.int32)
+    return dict(T=np.ascontiguousarray(d['T']), vec=vec, idx=idx)
+
+
+class anchored:
+    """Context manager: oracle solves inside refactor from `anchor` (see make_anchor)."""
+
+    def __init__(self, anchor):
+        self.a = anchor
+
+    def __enter__(self):
+        lib().mipx_oracle_set_anchor(_p(self.a['T'], _dp), _p(self.a['vec'], _dp), _p(self.a['idx'], _i32p))
+
+    def __exit__(self, *exc):
+        lib().mipx_oracle_set_anchor(None, None, None)

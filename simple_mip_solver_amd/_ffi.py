@@ -17,7 +17,8 @@ ERRORS = {-1: 'MIPX_EINVAL', -2: 'MIPX_ENODEV', -3: 'MIPX_EHIP', -4: 'MIPX_ETOOB
 # every symbol include/mipx.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     'mipx_abi_version', 'mipx_device_count', 'mipx_ctx_create', 'mipx_ctx_destroy',
-    'mipx_last_error', 'mipx_ctx_sync', 'mipx_problem_create', 'mipx_problem_destroy',
+    'mipx_last_error', 'mipx_ctx_sync', 'mipx_problem_create', 'mipx_problem_destroy', 'mipx_problem_set_anchor',
+    'mipx_tree_set_anchor_mode',
     'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_lp_solve_multi', 'mipx_gomory_batch', 'mipx_cut_select_batch', 'mipx_dev_alloc', 'mipx_dev_free',
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
@@ -75,6 +76,8 @@ def lib():
     L.mipx_ctx_sync.argtypes = [_vp]
     L.mipx_problem_create.argtypes = [_vp, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(_vp)]
     L.mipx_problem_destroy.argtypes = [_vp]
+    L.mipx_problem_set_anchor.argtypes = [_vp, _vp]
+    L.mipx_tree_set_anchor_mode.argtypes = [_vp, C.c_int]
     L.mipx_problem_destroy.restype = None
     solve_args = [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     L.mipx_lp_solve_batch.argtypes = solve_args
@@ -233,6 +236,11 @@ class Problem:
         ctx.check(rc, f'mipx_problem_create(m={self.m}, n={self.n})')
         self._h = h
 
+    def set_anchor(self, vstat):
+        """Anchor warm starts at the tableau of basis `vstat` (None switches it off)."""
+        v = None if vstat is None else np.ascontiguousarray(vstat, dtype=np.int8).reshape(self.n + self.m)
+        self.ctx.check(lib().mipx_problem_set_anchor(self._h, _ptr(v)), 'mipx_problem_set_anchor')
+
     def solve_batch(self, l, u, vstat=None, max_iter=0):
         """Host-buffer batched LP relaxation; returns dict like the oracle's."""
         n, m = self.n, self.m
@@ -363,6 +371,10 @@ class Tree:
     def keep_shard(self, rank, world):
         self.problem.ctx.check(lib().mipx_tree_keep_shard(self._h, int(rank), int(world)),
                                'mipx_tree_keep_shard')
+
+    def set_anchor_mode(self, on=True):
+        self.problem.ctx.check(lib().mipx_tree_set_anchor_mode(self._h, int(on)),
+                               'mipx_tree_set_anchor_mode')
 
     def set_trace(self, on=True):
         self.problem.ctx.check(lib().mipx_tree_set_trace(self._h, int(on)), 'mipx_tree_set_trace')

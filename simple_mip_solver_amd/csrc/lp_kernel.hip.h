@@ -38,6 +38,12 @@ struct LpArgs {
     const double *l, *u;           // batch x n
     const int8_t *vstat_in;        // batch x (n+m) or nullptr
     const int32_t *slot;           // optional: node k reads l/u/vstat_in at row slot[k] (node pool)
+    // optional anchor: tableau state of some basis of the same rows (layout of the dump: T m x n,
+    // vec = [d (n) | beta0 (m) | ..], idx = [nvar (n) | bvar (m) | ..]); warm starts refactor from it
+    // instead of from the slack basis (fewer pivots when the bases are close, e.g. the root's)
+    const double *anchor_T, *anchor_vec;
+    const int32_t *anchor_idx;
+    int refactor_only;             // stop after the refactorisation (used to build an anchor)
     int max_iter;
     int32_t *status;
     double *obj;
@@ -128,9 +134,11 @@ struct Smem {
     int bvar[MP];
     int nvar[NP];
     int side[NP];      // 0 lower, 1 upper, 2 fake upper
-    int wlist[NP];     // structurals the warm start wants basic, ascending
+    int wlist[NP];     // columns of the variables the warm start wants basic, ascending variable
     int nw;
     int ci[4];         // control words published by the control waves
+    int pos[NP + MP];  // column of each variable in the starting tableau, -1 if basic
+    int8_t entered[MP];// rows pivoted by the refactorisation
     double cd[2];
     int8_t wantb[NP + MP];
     int8_t atup[NP + MP];
@@ -169,28 +177,31 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
         const double *uk = g.u + src * n;
         const int8_t *vin = g.vstat_in ? g.vstat_in + src * nv : nullptr;
 
-        // ---- 0. T = -A, beta0 = -b, d = c, slack basis -------------------------------------
+        // ---- 0. T = -A, beta0 = -b, d = c, slack basis (or the anchor's tableau state) -------
+        const bool anchored = g.anchor_T != nullptr && vin != nullptr;
+        const double sgn = anchored ? 1.0 : -1.0;
 #pragma unroll
         for (int ii = 0; ii < R; ii++) {
             const int i = bi + TBI * ii;
-            const double *arow = gA + (size_t)(i < m ? i : 0) * n + bj;  // one base per row
+            const double *arow = (anchored ? g.anchor_T : gA) + (size_t)(i < m ? i : 0) * n + bj;
 #pragma unroll
             for (int jj = 0; jj < C; jj++) {
                 const int j = bj + TBJ * jj;
-                T[ii][jj] = (i < m && j < n) ? -arow[TBJ * jj] : 0.0;
+                T[ii][jj] = (i < m && j < n) ? sgn * arow[TBJ * jj] : 0.0;
             }
         }
 #pragma unroll 1
         for (int i = tid; i < MP; i += NT) {
-            s.beta0[i] = i < m ? -gb[i] : 0.0;
-            s.bvar[i] = i < m ? n + i : -1;
+            s.beta0[i] = i < m ? (anchored ? g.anchor_vec[n + i] : -gb[i]) : 0.0;
+            s.bvar[i] = i < m ? (anchored ? g.anchor_idx[n + i] : n + i) : -1;
             s.ba[i] = 0.0;
             s.bb[i] = 0.0;
+            s.entered[i] = 0;
         }
 #pragma unroll 1
         for (int j = tid; j < NP; j += NT) {
-            s.d[j] = j < n ? gc[j] : 0.0;
-            s.nvar[j] = j < n ? j : -1;
+            s.d[j] = j < n ? (anchored ? g.anchor_vec[j] : gc[j]) : 0.0;
+            s.nvar[j] = j < n ? (anchored ? g.anchor_idx[j] : j) : -1;
             s.lo[j] = j < n ? lk[j] : 0.0;
             s.up[j] = j < n ? uk[j] : 0.0;
             s.side[j] = 0;
@@ -202,15 +213,18 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
             int8_t st = (vin && v < nv) ? vin[v] : (int8_t)0;
             s.wantb[v] = st == 1;
             s.atup[v] = st == 2;
+            s.pos[v] = -1;
         }
         __syncthreads();
-        if (tid < 64) {  // compact list of structurals to pivot in (ascending)
+        for (int j = tid; j < n; j += NT) s.pos[s.nvar[j]] = j;
+        __syncthreads();
+        if (tid < 64) {  // columns of the variables to pivot in, in ascending variable order
             int cnt = 0;
-            for (int base = 0; base < n; base += 64) {
-                const int j = base + lane;
-                const bool w = j < n && s.wantb[j];
+            for (int base = 0; base < nv; base += 64) {
+                const int v = base + lane;
+                const bool w = v < nv && s.wantb[v] && s.pos[v] >= 0;
                 const unsigned long long mask = __ballot(w);
-                if (w) s.wlist[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+                if (w) s.wlist[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = s.pos[v];
                 cnt += __popcll(mask);
             }
             if (lane == 0) s.nw = cnt;
@@ -236,7 +250,11 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
 
             if (phase == 0) {
                 // ---- 1. refactor: pivot the next wanted structural into the basis -----------
-                if (w >= nw) { phase = 1; continue; }
+                if (w >= nw) {
+                    if (g.refactor_only) { status = 3; break; }
+                    phase = 1;
+                    continue;
+                }
                 q = __builtin_amdgcn_readfirstlane(s.wlist[w]);
                 w++;
                 {   // column q -> s.alpha
@@ -258,11 +276,11 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                     for (int kk = 0; kk < PI; kk++) {
                         const int i = lane + 64 * kk;
                         if (i < m) {
-                            const int bv = s.bvar[i];
+                            const bool wanted = s.wantb[s.bvar[i]];
                             const double a = fabs(s.alpha[i]);
-                            const bool ok = bv >= n && a > kPivTol;
-                            keep(k2, p2, a, i, ok);
-                            keep(k1, p1, a, i, ok && !s.wantb[bv >= n ? bv : n]);
+                            const bool ok = a > kPivTol;
+                            keep(k1, p1, a, i, ok && !wanted);
+                            keep(k2, p2, a, i, ok && wanted && !s.entered[i]);
                         }
                     }
                     double km;
@@ -558,6 +576,7 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                     const int tmp = s.bvar[r];
                     s.bvar[r] = s.nvar[q];
                     s.nvar[q] = tmp;
+                    if (!vals) s.entered[r] = 1;
                 }
             }
             __syncthreads();

@@ -33,6 +33,10 @@ struct mipx_problem {
     // K1b (tableau streamed from HBM): one m x n slab per concurrently resident workgroup
     double *big_scratch = nullptr;
     int big_slabs = 0;
+    // anchor tableau (mipx_problem_set_anchor): warm starts refactor from it
+    double *anchor_T = nullptr, *anchor_vec = nullptr;
+    int32_t *anchor_idx = nullptr;
+    bool anchor_on = false;
 };
 
 namespace {
@@ -203,6 +207,9 @@ void mipx_problem_destroy(mipx_problem *p) {
     if (p->dbg_vec) (void)hipFree(p->dbg_vec);
     if (p->dbg_idx) (void)hipFree(p->dbg_idx);
     if (p->big_scratch) (void)hipFree(p->big_scratch);
+    if (p->anchor_T) (void)hipFree(p->anchor_T);
+    if (p->anchor_vec) (void)hipFree(p->anchor_vec);
+    if (p->anchor_idx) (void)hipFree(p->anchor_idx);
     delete p;
 }
 
@@ -220,6 +227,10 @@ int mipx_lp_solve_batch_dev(mipx_problem *p, int batch, const double *l, const d
     a.A = p->dA; a.b = p->db; a.c = p->dc;
     a.A_stride = a.b_stride = a.c_stride = 0;
     a.l = l; a.u = u; a.vstat_in = vstat_in; a.slot = nullptr; a.max_iter = max_iter;
+    a.anchor_T = p->anchor_on ? p->anchor_T : nullptr;
+    a.anchor_vec = p->anchor_on ? p->anchor_vec : nullptr;
+    a.anchor_idx = p->anchor_on ? p->anchor_idx : nullptr;
+    a.refactor_only = 0;
     a.status = status; a.obj = obj; a.x = x; a.y = y; a.vstat_out = vstat_out;
     a.iters = iters; a.npivots = npivots; a.batch = batch;
     a.dbg_T = p->dbg_T; a.dbg_vec = p->dbg_vec; a.dbg_idx = p->dbg_idx; a.dbg_all = 0;
@@ -269,6 +280,44 @@ int mipx_lp_solve_batch(mipx_problem *p, int batch, const double *l, const doubl
     if (iters) HIP_TRY(ctx, hipMemcpyAsync(iters, base + o_it, B * 4, hipMemcpyDeviceToHost, st));
     if (npivots) HIP_TRY(ctx, hipMemcpyAsync(npivots, base + o_np, B * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    return MIPX_OK;
+}
+
+int mipx_problem_set_anchor(mipx_problem *p, const int8_t *vstat) {
+    if (!p) return MIPX_EINVAL;
+    mipx_ctx *ctx = p->ctx;
+    if (!vstat) { p->anchor_on = false; return MIPX_OK; }
+    const KernelCfg *cfg = pick_cfg(p->m, p->n);
+    if (!cfg) return fail(ctx, MIPX_ETOOBIG, "mipx_problem_set_anchor: only for the register-resident tiles");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t m = p->m ? p->m : 1, n = p->n, nv = n + p->m;
+    if (!p->anchor_T) {
+        HIP_TRY(ctx, hipMalloc((void **)&p->anchor_T, m * n * 8));
+        HIP_TRY(ctx, hipMalloc((void **)&p->anchor_vec, (n + 3 * m) * 8));
+        HIP_TRY(ctx, hipMalloc((void **)&p->anchor_idx, (2 * n + m) * 4));
+    }
+    double *zeros = nullptr;
+    int8_t *dv = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&zeros, n * 8));
+    HIP_TRY(ctx, hipMalloc((void **)&dv, nv));
+    HIP_TRY(ctx, hipMemset(zeros, 0, n * 8));
+    HIP_TRY(ctx, hipMemcpy(dv, vstat, nv, hipMemcpyHostToDevice));
+    mipx::LpArgs a;
+    a.m = p->m; a.n = p->n;
+    a.A = p->dA; a.b = p->db; a.c = p->dc;
+    a.A_stride = a.b_stride = a.c_stride = 0;
+    a.l = zeros; a.u = zeros; a.vstat_in = dv; a.slot = nullptr; a.max_iter = 0;
+    a.anchor_T = nullptr; a.anchor_vec = nullptr; a.anchor_idx = nullptr; a.refactor_only = 1;
+    a.status = nullptr; a.obj = nullptr; a.x = nullptr; a.y = nullptr; a.vstat_out = nullptr;
+    a.iters = nullptr; a.npivots = nullptr; a.batch = 1;
+    a.dbg_T = p->anchor_T; a.dbg_vec = p->anchor_vec; a.dbg_idx = p->anchor_idx; a.dbg_all = 0;
+    cfg->launch(a, 1, ctx->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(zeros);
+    (void)hipFree(dv);
+    if (e != hipSuccess) return fail(ctx, MIPX_EHIP, "mipx_problem_set_anchor", e);
+    p->anchor_on = true;
     return MIPX_OK;
 }
 
@@ -330,6 +379,7 @@ int mipx_lp_solve_multi(mipx_ctx *ctx, int m, int n, int batch, const double *A,
         a.A_stride = (size_t)m * nn; a.b_stride = (size_t)m; a.c_stride = nn;
         a.l = (const double *)(base + o_l); a.u = (const double *)(base + o_u);
         a.vstat_in = nullptr; a.slot = nullptr; a.max_iter = max_iter;
+    a.anchor_T = nullptr; a.anchor_vec = nullptr; a.anchor_idx = nullptr; a.refactor_only = 0;
         a.status = (int32_t *)(base + o_st); a.obj = (double *)(base + o_obj);
         a.x = (double *)(base + o_x); a.y = nullptr; a.vstat_out = (int8_t *)(base + o_v);
         a.iters = (int32_t *)(base + o_it); a.npivots = (int32_t *)(base + o_np); a.batch = batch;
@@ -384,6 +434,7 @@ int mipx_gomory_batch(mipx_problem *p, int batch, const double *l, const double 
         a.A_stride = a.b_stride = a.c_stride = 0;
         a.l = (const double *)(base + o_l); a.u = (const double *)(base + o_u);
         a.vstat_in = (const int8_t *)(base + o_v); a.slot = nullptr; a.max_iter = 0;
+        a.anchor_T = nullptr; a.anchor_vec = nullptr; a.anchor_idx = nullptr; a.refactor_only = 0;
         a.status = nullptr; a.obj = nullptr; a.x = nullptr; a.y = nullptr; a.vstat_out = nullptr;
         a.iters = nullptr; a.npivots = nullptr; a.batch = batch;
         a.dbg_T = (double *)(base + o_T); a.dbg_vec = (double *)(base + o_vec);

@@ -113,6 +113,7 @@ struct mipx_tree {
     std::vector<int32_t> tr_status, tr_bidx;
     std::vector<double> tr_obj;
     bool trace = false;
+    bool anchor_mode = false, anchor_set = false;
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // MIPX_TREE_PROFILE=1: host-side breakdown
 };
 
@@ -158,6 +159,10 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
     a.A = t->prob->dA; a.b = t->prob->db; a.c = t->prob->dc;
     a.A_stride = a.b_stride = a.c_stride = 0;
     a.l = l; a.u = u; a.vstat_in = v; a.slot = slot; a.max_iter = max_iter;
+    a.anchor_T = t->prob->anchor_on ? t->prob->anchor_T : nullptr;
+    a.anchor_vec = t->prob->anchor_on ? t->prob->anchor_vec : nullptr;
+    a.anchor_idx = t->prob->anchor_on ? t->prob->anchor_idx : nullptr;
+    a.refactor_only = 0;
     a.status = status; a.obj = obj; a.x = x; a.y = nullptr; a.vstat_out = vout;
     a.iters = iters; a.npivots = npiv; a.batch = batch;
     a.dbg_T = nullptr; a.dbg_vec = nullptr; a.dbg_idx = nullptr; a.dbg_all = 0;
@@ -403,6 +408,14 @@ int tree_step(mipx_tree *t, int want) {
         t->have_x = true;
     }
     t->phase_ms[3] += ms_since(tp); tp = now();
+    // anchor mode: the refactorisations of every later node start from the root's optimal tableau
+    if (t->anchor_mode && !t->anchor_set && ids[0] == 0 && status[0] == 0) {
+        std::vector<int8_t> rootv(nv);
+        HIP_TRY(ctx, hipMemcpy(rootv.data(), t->d_vout, (size_t)nv, hipMemcpyDeviceToHost));
+        const int arc = mipx_problem_set_anchor(t->prob, rootv.data());
+        if (arc) return arc;
+        t->anchor_set = true;
+    }
     // 5. children records on the device, then release the evaluated nodes' rows
     const int P = (int)br_pos.size();
     if (P > 0) {
@@ -514,6 +527,12 @@ void mipx_tree_destroy(mipx_tree *t) {
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete t;
+}
+
+int mipx_tree_set_anchor_mode(mipx_tree *t, int on) {
+    if (!t) return MIPX_EINVAL;
+    t->anchor_mode = on != 0;
+    return MIPX_OK;
 }
 
 int mipx_tree_set_trace(mipx_tree *t, int on) {

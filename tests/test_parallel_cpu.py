@@ -44,13 +44,17 @@ WORKER = textwrap.dedent('''
 def test_two_rank_exchange_over_gloo(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER.format(root=ROOT))
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-                          '--nproc-per-node=2', '--master-addr', '127.0.0.1', '--master-port',
-                          str(port), str(script)], env=env, capture_output=True, text=True,
-                         timeout=300)
+    res = None
+    for attempt in range(3):  # the free port is probed, not reserved: retry on a rendezvous clash
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                              '--nproc-per-node=2', '--master-addr', '127.0.0.1', '--master-port',
+                              str(port), str(script)], env=env, capture_output=True, text=True,
+                             timeout=300)
+        if res.returncode == 0:
+            break
     assert res.returncode == 0, res.stdout + res.stderr
     assert 'rank 0 ok' in res.stdout and 'rank 1 ok' in res.stdout
