@@ -69,6 +69,20 @@ struct PyHeap {
     size_t size() const { return h.size(); }
 };
 
+// Per-step device outputs and host staging, double-buffered so that the host bookkeeping of step
+// k overlaps the node-LP kernel of step k+1 (frontier batches > 1).
+struct StepBuf {
+    int32_t *d_slot = nullptr, *d_status = nullptr, *d_iters = nullptr, *d_npiv = nullptr,
+            *d_bidx = nullptr, *d_mipf = nullptr, *d_nprobe = nullptr, *d_plist = nullptr;
+    double *d_obj = nullptr, *d_x = nullptr, *d_bval = nullptr;
+    int8_t *d_vout = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, done = nullptr;
+    std::vector<int64_t> ids;
+    std::vector<int32_t> slots, br_pos, br_slot, br_var, br_child;  // staging kept alive
+    int B = 0;
+    bool in_flight = false;
+};
+
 struct mipx_tree {
     mipx_problem *prob = nullptr;
     mipx_ctx *ctx = nullptr;
@@ -79,13 +93,11 @@ struct mipx_tree {
     // device pool + per-step buffers
     double *pool_l = nullptr, *pool_u = nullptr;
     int8_t *pool_v = nullptr;
-    int32_t *d_int_idx = nullptr, *d_slot = nullptr, *d_status = nullptr, *d_iters = nullptr,
-            *d_npiv = nullptr, *d_bidx = nullptr, *d_mipf = nullptr, *d_nprobe = nullptr,
-            *d_plist = nullptr, *d_pairs = nullptr;
-    double *d_obj = nullptr, *d_x = nullptr, *d_cost_l = nullptr, *d_cost_r = nullptr,
-           *d_bval = nullptr;
-    int8_t *d_vout = nullptr;
+    int32_t *d_int_idx = nullptr, *d_pairs = nullptr;
+    double *d_cost_l = nullptr, *d_cost_r = nullptr;
     uint8_t *d_has = nullptr;
+    StepBuf buf[2];
+    bool table_dirty = false, pipeline = true;
     // probe pool (strong branching)
     int64_t probe_cap = 0;
     double *pp_l = nullptr, *pp_u = nullptr, *pp_obj = nullptr;
@@ -169,14 +181,14 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
     return launch_lp_any(t->prob, a, batch);
 }
 
-int launch_score(mipx_tree *t, int batch) {
+int launch_score(mipx_tree *t, StepBuf &S, int batch) {
     mipx::ScoreArgs s;
     s.n = t->n; s.n_int = t->n_int; s.batch = batch; s.rule = t->rule;
-    s.int_idx = t->d_int_idx; s.x = t->d_x; s.status = t->d_status;
+    s.int_idx = t->d_int_idx; s.x = S.d_x; s.status = S.d_status;
     s.cost_l = t->d_cost_l; s.cost_r = t->d_cost_r; s.has_entry = t->d_has;
-    s.branch_idx = t->d_bidx; s.branch_val = t->d_bval; s.mip_feasible = t->d_mipf;
-    s.n_probe = t->d_nprobe;
-    s.probe_list = t->d_plist;
+    s.branch_idx = S.d_bidx; s.branch_val = S.d_bval; s.mip_feasible = S.d_mipf;
+    s.n_probe = S.d_nprobe;
+    s.probe_list = S.d_plist;
     hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, t->ctx->stream, s);
     HIP_TRY(t->ctx, hipGetLastError());
     return MIPX_OK;
@@ -196,19 +208,19 @@ void pc_update(mipx_tree *t, int var, int dir, int lp_status, double objective, 
     t->has_entry[var] = 1;
 }
 
-int tree_step(mipx_tree *t, int want) {
+// First half of a step: pop the batch and enqueue its node LPs + scoring (no host wait).
+int tree_launch(mipx_tree *t, StepBuf &S, int want) {
     mipx_ctx *ctx = t->ctx;
-    const int n = t->n, nv = t->n + t->m;
-    const double inf = std::numeric_limits<double>::infinity();
     hipStream_t st = ctx->stream;
     auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
-        return std::chrono::duration<double, std::milli>(now() - t0).count();
-    };
     auto tp = now();
     // 1. pop the batch (a node whose inherited bound cannot beat the incumbent is closed unevaluated)
-    std::vector<int64_t> ids;
-    std::vector<int32_t> slots;
+    std::vector<int64_t> &ids = S.ids;
+    std::vector<int32_t> &slots = S.slots;
+    ids.clear();
+    slots.clear();
+    S.B = 0;
+    S.in_flight = false;
     while ((int)ids.size() < want && !t->heap.empty()) {
         const int64_t id = t->heap.pop();
         t->is_open[id] = 0;
@@ -224,30 +236,60 @@ int tree_step(mipx_tree *t, int want) {
     }
     const int B = (int)ids.size();
     if (B == 0) return MIPX_OK;
+    S.B = B;
+    S.in_flight = true;
     t->steps++;
-    t->phase_ms[0] += ms_since(tp); tp = now();
-    HIP_TRY(ctx, hipMemcpyAsync(t->d_slot, slots.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    t->phase_ms[0] += std::chrono::duration<double, std::milli>(now() - tp).count();
+    if (t->table_dirty) {  // pseudo-cost table as of the last finished step
+        const size_t n = t->n;
+        HIP_TRY(ctx, hipMemcpyAsync(t->d_cost_l, t->cost_l.data(), n * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(t->d_cost_r, t->cost_r.data(), n * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(t->d_has, t->has_entry.data(), n, hipMemcpyHostToDevice, st));
+        t->table_dirty = false;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(S.d_slot, slots.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     // 2. LP relaxations + scoring
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
-    int rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, t->d_slot, 0, t->d_status, t->d_obj,
-                       t->d_x, t->d_vout, t->d_iters, t->d_npiv);
+    HIP_TRY(ctx, hipEventRecord(S.e0, st));
+    int rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, S.d_slot, 0, S.d_status, S.d_obj,
+                       S.d_x, S.d_vout, S.d_iters, S.d_npiv);
     if (rc) return rc;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
-    if ((rc = launch_score(t, B))) return rc;
+    HIP_TRY(ctx, hipEventRecord(S.e1, st));
+    if ((rc = launch_score(t, S, B))) return rc;
+    HIP_TRY(ctx, hipEventRecord(S.done, st));
+    return MIPX_OK;
+}
+
+// Second half: wait for that batch only, then the reference's bookkeeping and the children.
+int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
+    mipx_ctx *ctx = t->ctx;
+    const int n = t->n, nv = t->n + t->m;
+    const double inf = std::numeric_limits<double>::infinity();
+    hipStream_t st = ctx->stream;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(now() - t0).count();
+    };
+    auto tp = now();
+    const int B = S.B;
+    if (!S.in_flight || B == 0) return MIPX_OK;
+    S.in_flight = false;
+    const std::vector<int64_t> &ids = S.ids;
+    const std::vector<int32_t> &slots = S.slots;
+    int rc = MIPX_OK;
     std::vector<int32_t> status(B), bidx(B), mipf(B), nprobe(B), npiv(B);
     std::vector<double> obj(B), bval(B);
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipEventSynchronize(S.done));
     {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) t->kernel_ms += ms;
+        if (hipEventElapsedTime(&ms, S.e0, S.e1) == hipSuccess) t->kernel_ms += ms;
     }
-    HIP_TRY(ctx, hipMemcpy(status.data(), t->d_status, (size_t)B * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(obj.data(), t->d_obj, (size_t)B * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(bidx.data(), t->d_bidx, (size_t)B * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(bval.data(), t->d_bval, (size_t)B * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(mipf.data(), t->d_mipf, (size_t)B * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(nprobe.data(), t->d_nprobe, (size_t)B * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(npiv.data(), t->d_npiv, (size_t)B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(status.data(), S.d_status, (size_t)B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(obj.data(), S.d_obj, (size_t)B * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(bidx.data(), S.d_bidx, (size_t)B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(bval.data(), S.d_bval, (size_t)B * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(mipf.data(), S.d_mipf, (size_t)B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(nprobe.data(), S.d_nprobe, (size_t)B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(npiv.data(), S.d_npiv, (size_t)B * 4, hipMemcpyDeviceToHost));
     t->lps += B;
     for (int k = 0; k < B; k++) t->pivots += npiv[k];
     t->phase_ms[1] += ms_since(tp); tp = now();
@@ -270,17 +312,17 @@ int tree_step(mipx_tree *t, int want) {
             plist.resize((size_t)B * t->n_int);
             const bool bulk = askers > 64;
             if (bulk) {
-                HIP_TRY(ctx, hipMemcpy(plist.data(), t->d_plist, plist.size() * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(ctx, hipMemcpy(plist.data(), S.d_plist, plist.size() * 4, hipMemcpyDeviceToHost));
                 xall.resize((size_t)B * n);
-                HIP_TRY(ctx, hipMemcpy(xall.data(), t->d_x, xall.size() * 8, hipMemcpyDeviceToHost));
+                HIP_TRY(ctx, hipMemcpy(xall.data(), S.d_x, xall.size() * 8, hipMemcpyDeviceToHost));
             }
             std::vector<double> xone(n);
             for (int k = 0; k < B; k++) {
                 if (!nprobe[k]) continue;
                 if (!bulk) {
-                    HIP_TRY(ctx, hipMemcpy(plist.data() + (size_t)k * t->n_int, t->d_plist + (size_t)k * t->n_int,
+                    HIP_TRY(ctx, hipMemcpy(plist.data() + (size_t)k * t->n_int, S.d_plist + (size_t)k * t->n_int,
                                            (size_t)nprobe[k] * 4, hipMemcpyDeviceToHost));
-                    HIP_TRY(ctx, hipMemcpy(xone.data(), t->d_x + (size_t)k * n, (size_t)n * 8, hipMemcpyDeviceToHost));
+                    HIP_TRY(ctx, hipMemcpy(xone.data(), S.d_x + (size_t)k * n, (size_t)n * 8, hipMemcpyDeviceToHost));
                 }
                 const double *xk = bulk ? xall.data() + (size_t)k * n : xone.data();
                 for (int e = 0; e < nprobe[k]; e++) {
@@ -303,7 +345,7 @@ int tree_step(mipx_tree *t, int want) {
             ca.n = n; ca.m = t->m; ca.count = P;
             ca.src_l = t->pool_l; ca.src_u = t->pool_u;
             ca.parent_slot = t->d_pairs; ca.parent_pos = t->d_pairs + P; ca.var = t->d_pairs + 2 * P;
-            ca.x = t->d_x; ca.vstat = t->d_vout;
+            ca.x = S.d_x; ca.vstat = S.d_vout;
             ca.dst_l = t->pp_l; ca.dst_u = t->pp_u; ca.dst_v = t->pp_v;
             ca.child_slot = t->d_pairs + 3 * P;
             hipLaunchKernelGGL(mipx::make_children, dim3(2 * P), dim3(256), 0, st, ca);
@@ -347,20 +389,26 @@ int tree_step(mipx_tree *t, int want) {
                 e += 0;
             }
         }
-        if (changed) {
+        if (changed) t->table_dirty = true;
+        // re-score with the updated table: always in the sequential mode (the reference branches
+        // with the table its own node just updated); when steps overlap, only if probes created
+        // entries that the first scoring had to leave out (the wait covers the step in flight)
+        if (changed && (!overlapped || total > 0)) {
             HIP_TRY(ctx, hipMemcpyAsync(t->d_cost_l, t->cost_l.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
             HIP_TRY(ctx, hipMemcpyAsync(t->d_cost_r, t->cost_r.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
             HIP_TRY(ctx, hipMemcpyAsync(t->d_has, t->has_entry.data(), (size_t)n, hipMemcpyHostToDevice, st));
-            if ((rc = launch_score(t, B))) return rc;
+            t->table_dirty = false;
+            if ((rc = launch_score(t, S, B))) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(st));
-            HIP_TRY(ctx, hipMemcpy(bidx.data(), t->d_bidx, (size_t)B * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(ctx, hipMemcpy(bval.data(), t->d_bval, (size_t)B * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(bidx.data(), S.d_bidx, (size_t)B * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(bval.data(), S.d_bval, (size_t)B * 8, hipMemcpyDeviceToHost));
         }
     }
 
     t->phase_ms[2] += ms_since(tp); tp = now();
     // 4. the reference's _evaluate_node bookkeeping, node by node
-    std::vector<int32_t> br_pos, br_slot, br_var, br_child;
+    std::vector<int32_t> &br_pos = S.br_pos, &br_slot = S.br_slot, &br_var = S.br_var, &br_child = S.br_child;
+    br_pos.clear(); br_slot.clear(); br_var.clear(); br_child.clear();
     int incumbent_pos = -1;
     for (int k = 0; k < B; k++) {
         const int64_t id = ids[k];
@@ -403,7 +451,7 @@ int tree_step(mipx_tree *t, int want) {
     }
     if (incumbent_pos >= 0) {
         // the last improving node of the batch holds the incumbent
-        HIP_TRY(ctx, hipMemcpy(t->best_x.data(), t->d_x + (size_t)incumbent_pos * n, (size_t)n * 8,
+        HIP_TRY(ctx, hipMemcpy(t->best_x.data(), S.d_x + (size_t)incumbent_pos * n, (size_t)n * 8,
                                hipMemcpyDeviceToHost));
         t->have_x = true;
     }
@@ -411,7 +459,7 @@ int tree_step(mipx_tree *t, int want) {
     // anchor mode: the refactorisations of every later node start from the root's optimal tableau
     if (t->anchor_mode && !t->anchor_set && ids[0] == 0 && status[0] == 0) {
         std::vector<int8_t> rootv(nv);
-        HIP_TRY(ctx, hipMemcpy(rootv.data(), t->d_vout, (size_t)nv, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(rootv.data(), S.d_vout, (size_t)nv, hipMemcpyDeviceToHost));
         const int arc = mipx_problem_set_anchor(t->prob, rootv.data());
         if (arc) return arc;
         t->anchor_set = true;
@@ -427,12 +475,12 @@ int tree_step(mipx_tree *t, int want) {
         ca.n = n; ca.m = t->m; ca.count = P;
         ca.src_l = t->pool_l; ca.src_u = t->pool_u;
         ca.parent_slot = t->d_pairs; ca.parent_pos = t->d_pairs + P; ca.var = t->d_pairs + 2 * P;
-        ca.x = t->d_x; ca.vstat = t->d_vout;
+        ca.x = S.d_x; ca.vstat = S.d_vout;
         ca.dst_l = t->pool_l; ca.dst_u = t->pool_u; ca.dst_v = t->pool_v;
         ca.child_slot = t->d_pairs + 3 * P;
         hipLaunchKernelGGL(mipx::make_children, dim3(2 * P), dim3(256), 0, st, ca);
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipStreamSynchronize(st));  // the staging vectors above die with this scope
+        if (!overlapped) HIP_TRY(ctx, hipStreamSynchronize(st));
     }
     for (int k = 0; k < B; k++) {
         t->free_slots.push_back(slots[k]);
@@ -473,15 +521,19 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     int rc = 0;
     rc |= dmalloc(ctx, &t->pool_l, cap * n); rc |= dmalloc(ctx, &t->pool_u, cap * n);
     rc |= dmalloc(ctx, &t->pool_v, cap * nv);
-    rc |= dmalloc(ctx, &t->d_int_idx, (size_t)n_int); rc |= dmalloc(ctx, &t->d_slot, B);
-    rc |= dmalloc(ctx, &t->d_status, B); rc |= dmalloc(ctx, &t->d_iters, B);
-    rc |= dmalloc(ctx, &t->d_npiv, B); rc |= dmalloc(ctx, &t->d_bidx, B);
-    rc |= dmalloc(ctx, &t->d_mipf, B); rc |= dmalloc(ctx, &t->d_nprobe, B);
-    rc |= dmalloc(ctx, &t->d_plist, B * (size_t)(n_int ? n_int : 1));
+    rc |= dmalloc(ctx, &t->d_int_idx, (size_t)n_int);
     rc |= dmalloc(ctx, &t->d_pairs, 5 * (pc / 2 > B ? pc / 2 : B));
-    rc |= dmalloc(ctx, &t->d_obj, B); rc |= dmalloc(ctx, &t->d_x, B * n);
-    rc |= dmalloc(ctx, &t->d_bval, B);
-    rc |= dmalloc(ctx, &t->d_vout, B * nv);
+    for (StepBuf &S : t->buf) {
+        rc |= dmalloc(ctx, &S.d_slot, B); rc |= dmalloc(ctx, &S.d_status, B);
+        rc |= dmalloc(ctx, &S.d_iters, B); rc |= dmalloc(ctx, &S.d_npiv, B);
+        rc |= dmalloc(ctx, &S.d_bidx, B); rc |= dmalloc(ctx, &S.d_mipf, B);
+        rc |= dmalloc(ctx, &S.d_nprobe, B);
+        rc |= dmalloc(ctx, &S.d_plist, B * (size_t)(n_int ? n_int : 1));
+        rc |= dmalloc(ctx, &S.d_obj, B); rc |= dmalloc(ctx, &S.d_x, B * n);
+        rc |= dmalloc(ctx, &S.d_bval, B); rc |= dmalloc(ctx, &S.d_vout, B * nv);
+        if (hipEventCreate(&S.e0) != hipSuccess || hipEventCreate(&S.e1) != hipSuccess ||
+            hipEventCreate(&S.done) != hipSuccess) rc |= MIPX_EHIP;
+    }
     rc |= dmalloc(ctx, &t->d_cost_l, n); rc |= dmalloc(ctx, &t->d_cost_r, n);
     rc |= dmalloc(ctx, &t->d_has, n);
     if (branch_rule == 1) {
@@ -520,12 +572,20 @@ void mipx_tree_destroy(mipx_tree *t) {
                      "bookkeeping %.1f ms  children %.1f ms  (lp kernel %.1f ms)\n", (long long)t->steps,
                      t->phase_ms[0], t->phase_ms[1], t->phase_ms[2], t->phase_ms[3], t->phase_ms[4], t->kernel_ms);
     if (t->ctx) (void)hipSetDevice(t->ctx->device);
-    void *ptrs[] = {t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_slot, t->d_status, t->d_iters,
-                    t->d_npiv, t->d_bidx, t->d_mipf, t->d_nprobe, t->d_plist, t->d_pairs, t->d_obj,
-                    t->d_x, t->d_bval, t->d_vout, t->d_cost_l, t->d_cost_r, t->d_has, t->pp_l, t->pp_u, t->pp_v,
-                    t->pp_obj, t->pp_status};
+    if (t->ctx && t->ctx->stream) (void)hipStreamSynchronize(t->ctx->stream);
+    void *ptrs[] = {t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_pairs, t->d_cost_l,
+                    t->d_cost_r, t->d_has, t->pp_l, t->pp_u, t->pp_v, t->pp_obj, t->pp_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    for (StepBuf &S : t->buf) {
+        void *sp[] = {S.d_slot, S.d_status, S.d_iters, S.d_npiv, S.d_bidx, S.d_mipf, S.d_nprobe,
+                      S.d_plist, S.d_obj, S.d_x, S.d_bval, S.d_vout};
+        for (void *q : sp)
+            if (q) (void)hipFree(q);
+        if (S.e0) (void)hipEventDestroy(S.e0);
+        if (S.e1) (void)hipEventDestroy(S.e1);
+        if (S.done) (void)hipEventDestroy(S.done);
+    }
     delete t;
 }
 
@@ -564,20 +624,51 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
         tree_push(t, 0);
     }
     int64_t steps = 0;
-    for (;;) {
-        if (t->heap.empty() || t->unbounded) break;
-        if (node_limit > 0 && t->evaluated >= node_limit) break;
+    // With frontier batches > 1 the host half of step k (bookkeeping, children) overlaps the GPU
+    // half of step k+1, whose batch is popped before the children of step k exist.
+    const bool overlap = t->pipeline && frontier_batch > 1;
+    int cur = 0;
+    auto stop_now = [&](int64_t inflight) {
+        if (t->unbounded) return true;
+        if (node_limit > 0 && t->evaluated + inflight >= node_limit) return true;
         const double gap = tree_gap(t);
-        if (gap >= 0 && gap <= mip_gap) break;
+        if (gap >= 0 && gap <= mip_gap) return true;
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (max_seconds > 0 && el > max_seconds) break;
-        if (max_steps > 0 && steps >= max_steps) break;
+        if (max_seconds > 0 && el > max_seconds) return true;
+        if (max_steps > 0 && steps >= max_steps) return true;
+        return false;
+    };
+    auto batch_size = [&](int64_t inflight) {
         int want = frontier_batch;
-        if (node_limit > 0 && node_limit - t->evaluated < want) want = (int)(node_limit - t->evaluated);
-        const int rc = tree_step(t, want);
+        if (node_limit > 0 && node_limit - t->evaluated - inflight < want)
+            want = (int)(node_limit - t->evaluated - inflight);
+        return want;
+    };
+    if (!t->heap.empty() && !stop_now(0)) {
+        int rc = tree_launch(t, t->buf[cur], batch_size(0));
         if (rc) return rc;
-        steps++;
+        if (t->buf[cur].in_flight) steps++;
     }
+    while (t->buf[cur].in_flight) {
+        StepBuf &S = t->buf[cur], &N = t->buf[1 - cur];
+        if (overlap && !t->heap.empty() && !stop_now(S.B)) {
+            const int want = batch_size(S.B);
+            if (want > 0) {
+                int rc = tree_launch(t, N, want);
+                if (rc) return rc;
+                if (N.in_flight) steps++;
+            }
+        }
+        int rc = tree_finish(t, S, overlap);
+        if (rc) return rc;
+        if (!N.in_flight && !t->heap.empty() && !stop_now(0)) {
+            rc = tree_launch(t, N, batch_size(0));
+            if (rc) return rc;
+            if (N.in_flight) steps++;
+        }
+        cur = 1 - cur;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     t->solve_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double gap = tree_gap(t);
     if (t->unbounded) t->status = 3;
