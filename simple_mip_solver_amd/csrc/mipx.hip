@@ -89,10 +89,11 @@ bool big_fits(int m, int n) { return m >= 1 && m <= mipx::kBigMaxM && n <= mipx:
 bool shape_supported(int m, int n) { return pick_cfg(m, n) != nullptr || big_fits(m, n); }
 
 // Launch K1 (register-resident tableau) or, above its tiles, K1b (tableau streamed from HBM).
-int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch) {
+int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t stream = nullptr) {
     mipx_ctx *ctx = p->ctx;
+    if (!stream) stream = ctx->stream;
     if (const KernelCfg *cfg = pick_cfg(p->m, p->n)) {
-        cfg->launch(a, batch, ctx->stream);
+        cfg->launch(a, batch, stream);
         HIP_TRY(ctx, hipGetLastError());
         return MIPX_OK;
     }
@@ -108,7 +109,7 @@ int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch) {
     const size_t lds = mipx::big_lds_bytes(p->m, p->n);
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)mipx::lp_dual_simplex_big,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(mipx::lp_dual_simplex_big, dim3(slabs), dim3(mipx::kBigNT), lds, ctx->stream,
+    hipLaunchKernelGGL(mipx::lp_dual_simplex_big, dim3(slabs), dim3(mipx::kBigNT), lds, stream,
                        a, p->big_scratch);
     HIP_TRY(ctx, hipGetLastError());
     return MIPX_OK;

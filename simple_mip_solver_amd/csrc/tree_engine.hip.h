@@ -93,9 +93,10 @@ struct mipx_tree {
     // device pool + per-step buffers
     double *pool_l = nullptr, *pool_u = nullptr;
     int8_t *pool_v = nullptr;
-    int32_t *d_int_idx = nullptr, *d_pairs = nullptr;
-    double *d_cost_l = nullptr, *d_cost_r = nullptr;
-    uint8_t *d_has = nullptr;
+    int32_t *d_int_idx = nullptr, *d_pairs = nullptr, *d_pairs2 = nullptr;
+    double *d_cost_l = nullptr, *d_cost_r = nullptr, *d_cost_l2 = nullptr, *d_cost_r2 = nullptr;
+    uint8_t *d_has = nullptr, *d_has2 = nullptr;
+    hipStream_t st2 = nullptr;  // strong-branching probes + re-scoring run beside the step in flight
     StepBuf buf[2];
     bool table_dirty = false, pipeline = true;
     // probe pool (strong branching)
@@ -165,7 +166,7 @@ void tree_push(mipx_tree *t, int64_t id) {
 
 int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const int8_t *v,
               const int32_t *slot, int max_iter, int32_t *status, double *obj, double *x,
-              int8_t *vout, int32_t *iters, int32_t *npiv) {
+              int8_t *vout, int32_t *iters, int32_t *npiv, hipStream_t stream = nullptr) {
     mipx::LpArgs a;
     a.m = t->m; a.n = t->n;
     a.A = t->prob->dA; a.b = t->prob->db; a.c = t->prob->dc;
@@ -178,18 +179,19 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
     a.status = status; a.obj = obj; a.x = x; a.y = nullptr; a.vstat_out = vout;
     a.iters = iters; a.npivots = npiv; a.batch = batch;
     a.dbg_T = nullptr; a.dbg_vec = nullptr; a.dbg_idx = nullptr; a.dbg_all = 0;
-    return launch_lp_any(t->prob, a, batch);
+    return launch_lp_any(t->prob, a, batch, stream);
 }
 
-int launch_score(mipx_tree *t, StepBuf &S, int batch) {
+int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false) {
     mipx::ScoreArgs s;
     s.n = t->n; s.n_int = t->n_int; s.batch = batch; s.rule = t->rule;
     s.int_idx = t->d_int_idx; s.x = S.d_x; s.status = S.d_status;
-    s.cost_l = t->d_cost_l; s.cost_r = t->d_cost_r; s.has_entry = t->d_has;
+    s.cost_l = side ? t->d_cost_l2 : t->d_cost_l; s.cost_r = side ? t->d_cost_r2 : t->d_cost_r;
+    s.has_entry = side ? t->d_has2 : t->d_has;
     s.branch_idx = S.d_bidx; s.branch_val = S.d_bval; s.mip_feasible = S.d_mipf;
     s.n_probe = S.d_nprobe;
     s.probe_list = S.d_plist;
-    hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, t->ctx->stream, s);
+    hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, side ? t->st2 : t->ctx->stream, s);
     HIP_TRY(t->ctx, hipGetLastError());
     return MIPX_OK;
 }
@@ -302,6 +304,10 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         std::vector<double> xrow;  // x of the probed variables
         std::vector<int32_t> pst;
         std::vector<double> pobj;
+        // a step in flight on the main stream: probes and re-scoring go to the side stream (K1b
+        // shares one scratch slab per problem, so it stays on the main stream)
+        const bool use_side = overlapped && pick_cfg(t->m, t->n) != nullptr;
+        hipStream_t ps = use_side ? t->st2 : st;
         if (total > 0) {
             if (2 * total > t->probe_cap) return fail(ctx, MIPX_ENOMEM, "tree: probe pool exhausted");
             // probe lists and the probed values: read back only the rows of the nodes that asked
@@ -337,26 +343,28 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             child_slot.resize(2 * (size_t)P);
             for (int c = 0; c < 2 * P; c++) child_slot[c] = c;
             // d_pairs layout: [parent_slot | parent_pos | var | child_slot(2P)]
-            HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs, pair_slot.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs + P, pair_pos.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs + 2 * P, pair_var.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
-            HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs + 3 * P, child_slot.data(), (size_t)P * 8, hipMemcpyHostToDevice, st));
+            // (on the side stream when a step is in flight: the probes run beside its node LPs)
+            int32_t *dp = use_side ? t->d_pairs2 : t->d_pairs;
+            HIP_TRY(ctx, hipMemcpyAsync(dp, pair_slot.data(), (size_t)P * 4, hipMemcpyHostToDevice, ps));
+            HIP_TRY(ctx, hipMemcpyAsync(dp + P, pair_pos.data(), (size_t)P * 4, hipMemcpyHostToDevice, ps));
+            HIP_TRY(ctx, hipMemcpyAsync(dp + 2 * P, pair_var.data(), (size_t)P * 4, hipMemcpyHostToDevice, ps));
+            HIP_TRY(ctx, hipMemcpyAsync(dp + 3 * P, child_slot.data(), (size_t)P * 8, hipMemcpyHostToDevice, ps));
             mipx::ChildArgs ca;
             ca.n = n; ca.m = t->m; ca.count = P;
             ca.src_l = t->pool_l; ca.src_u = t->pool_u;
-            ca.parent_slot = t->d_pairs; ca.parent_pos = t->d_pairs + P; ca.var = t->d_pairs + 2 * P;
+            ca.parent_slot = dp; ca.parent_pos = dp + P; ca.var = dp + 2 * P;
             ca.x = S.d_x; ca.vstat = S.d_vout;
             ca.dst_l = t->pp_l; ca.dst_u = t->pp_u; ca.dst_v = t->pp_v;
-            ca.child_slot = t->d_pairs + 3 * P;
-            hipLaunchKernelGGL(mipx::make_children, dim3(2 * P), dim3(256), 0, st, ca);
+            ca.child_slot = dp + 3 * P;
+            hipLaunchKernelGGL(mipx::make_children, dim3(2 * P), dim3(256), 0, ps, ca);
             HIP_TRY(ctx, hipGetLastError());
             // truncated dual simplex on every probe (base_node.py:645-646)
             rc = launch_lp(t, 2 * P, t->pp_l, t->pp_u, t->pp_v, nullptr, t->sb_iters, t->pp_status,
-                           t->pp_obj, nullptr, nullptr, nullptr, nullptr);
+                           t->pp_obj, nullptr, nullptr, nullptr, nullptr, ps);
             if (rc) return rc;
             pst.resize(2 * (size_t)P);
             pobj.resize(2 * (size_t)P);
-            HIP_TRY(ctx, hipStreamSynchronize(st));
+            HIP_TRY(ctx, hipStreamSynchronize(ps));
             HIP_TRY(ctx, hipMemcpy(pst.data(), t->pp_status, pst.size() * 4, hipMemcpyDeviceToHost));
             HIP_TRY(ctx, hipMemcpy(pobj.data(), t->pp_obj, pobj.size() * 8, hipMemcpyDeviceToHost));
             t->probes += 2 * P;
@@ -394,12 +402,14 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         // with the table its own node just updated); when steps overlap, only if probes created
         // entries that the first scoring had to leave out (the wait covers the step in flight)
         if (changed && (!overlapped || total > 0)) {
-            HIP_TRY(ctx, hipMemcpyAsync(t->d_cost_l, t->cost_l.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-            HIP_TRY(ctx, hipMemcpyAsync(t->d_cost_r, t->cost_r.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-            HIP_TRY(ctx, hipMemcpyAsync(t->d_has, t->has_entry.data(), (size_t)n, hipMemcpyHostToDevice, st));
-            t->table_dirty = false;
-            if ((rc = launch_score(t, S, B))) return rc;
-            HIP_TRY(ctx, hipStreamSynchronize(st));
+            double *cl = use_side ? t->d_cost_l2 : t->d_cost_l, *cr = use_side ? t->d_cost_r2 : t->d_cost_r;
+            uint8_t *ch = use_side ? t->d_has2 : t->d_has;
+            HIP_TRY(ctx, hipMemcpyAsync(cl, t->cost_l.data(), (size_t)n * 8, hipMemcpyHostToDevice, ps));
+            HIP_TRY(ctx, hipMemcpyAsync(cr, t->cost_r.data(), (size_t)n * 8, hipMemcpyHostToDevice, ps));
+            HIP_TRY(ctx, hipMemcpyAsync(ch, t->has_entry.data(), (size_t)n, hipMemcpyHostToDevice, ps));
+            if (!use_side) t->table_dirty = false;
+            if ((rc = launch_score(t, S, B, use_side))) return rc;
+            HIP_TRY(ctx, hipStreamSynchronize(ps));
             HIP_TRY(ctx, hipMemcpy(bidx.data(), S.d_bidx, (size_t)B * 4, hipMemcpyDeviceToHost));
             HIP_TRY(ctx, hipMemcpy(bval.data(), S.d_bval, (size_t)B * 8, hipMemcpyDeviceToHost));
         }
@@ -523,6 +533,9 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     rc |= dmalloc(ctx, &t->pool_v, cap * nv);
     rc |= dmalloc(ctx, &t->d_int_idx, (size_t)n_int);
     rc |= dmalloc(ctx, &t->d_pairs, 5 * (pc / 2 > B ? pc / 2 : B));
+    rc |= dmalloc(ctx, &t->d_pairs2, 5 * (pc / 2 > B ? pc / 2 : B));
+    rc |= dmalloc(ctx, &t->d_cost_l2, n); rc |= dmalloc(ctx, &t->d_cost_r2, n); rc |= dmalloc(ctx, &t->d_has2, n);
+    if (hipStreamCreateWithFlags(&t->st2, hipStreamNonBlocking) != hipSuccess) rc |= MIPX_EHIP;
     for (StepBuf &S : t->buf) {
         rc |= dmalloc(ctx, &S.d_slot, B); rc |= dmalloc(ctx, &S.d_status, B);
         rc |= dmalloc(ctx, &S.d_iters, B); rc |= dmalloc(ctx, &S.d_npiv, B);
@@ -573,8 +586,9 @@ void mipx_tree_destroy(mipx_tree *t) {
                      t->phase_ms[0], t->phase_ms[1], t->phase_ms[2], t->phase_ms[3], t->phase_ms[4], t->kernel_ms);
     if (t->ctx) (void)hipSetDevice(t->ctx->device);
     if (t->ctx && t->ctx->stream) (void)hipStreamSynchronize(t->ctx->stream);
-    void *ptrs[] = {t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_pairs, t->d_cost_l,
-                    t->d_cost_r, t->d_has, t->pp_l, t->pp_u, t->pp_v, t->pp_obj, t->pp_status};
+    if (t->st2) { (void)hipStreamSynchronize(t->st2); (void)hipStreamDestroy(t->st2); }
+    void *ptrs[] = {t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_pairs, t->d_pairs2, t->d_cost_l,
+                    t->d_cost_r, t->d_has, t->d_cost_l2, t->d_cost_r2, t->d_has2, t->pp_l, t->pp_u, t->pp_v, t->pp_obj, t->pp_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (StepBuf &S : t->buf) {
