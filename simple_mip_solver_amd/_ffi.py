@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libmipx.so')
+LIB_PATH = os.environ.get('MIPX_LIB') or os.path.join(_HERE, 'csrc', 'libmipx.so')  # MIPX_LIB: a profiling build
 
 MIPX_OK = 0
 ERRORS = {-1: 'MIPX_EINVAL', -2: 'MIPX_ENODEV', -3: 'MIPX_EHIP', -4: 'MIPX_ETOOBIG',

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -93,9 +94,33 @@ int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t strea
     mipx_ctx *ctx = p->ctx;
     if (!stream) stream = ctx->stream;
     if (const KernelCfg *cfg = pick_cfg(p->m, p->n)) {
+#ifdef MIPX_KPROF
+        // profiling build: per-section cycle totals of wave 0, summed over the launch
+        static unsigned long long *d_prof = nullptr;
+        if (!d_prof) HIP_TRY(ctx, hipMalloc((void **)&d_prof, 16 * 8));
+        HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, 16 * 8, stream));
+        a.prof = d_prof;
+        cfg->launch(a, batch, stream);
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        unsigned long long h[16];
+        HIP_TRY(ctx, hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost));
+        if (getenv("MIPX_KPROF_PRINT")) {
+            const double it = h[12] ? (double)h[12] : 1.0, rf = h[13] ? (double)h[13] : 1.0;
+            const double lps = h[14] ? (double)h[14] : 1.0;
+            fprintf(stderr, "[kprof] %s batch %d  lps %llu iters %llu refactor pivots %llu\n"
+                    "  simplex cycles/iter: rowx %.0f ratio %.0f colx %.0f update+leave %.0f\n"
+                    "  refactor cycles/pivot: rowsel %.0f rowx %.0f update+colx %.0f\n"
+                    "  per LP: setup %.0f first colx %.0f value-init %.0f tail %.0f\n",
+                    cfg->name, batch, h[14], h[12], h[13], h[1] / it, h[3] / it, h[4] / it, h[0] / it,
+                    h[9] / rf, h[10] / rf, h[11] / rf, h[15] / lps, h[8] / lps, h[7] / lps, h[6] / lps);
+        }
+        return MIPX_OK;
+#else
+        a.prof = nullptr;
         cfg->launch(a, batch, stream);
         HIP_TRY(ctx, hipGetLastError());
         return MIPX_OK;
+#endif
     }
     if (!big_fits(p->m, p->n)) return fail(ctx, MIPX_ETOOBIG, "(m,n) exceeds every LP kernel");
     const int slabs = batch < 1024 ? batch : 1024;  // 1024 x 4 MiB = 4 GiB at 1024 x 512
