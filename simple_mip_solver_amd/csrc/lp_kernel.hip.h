@@ -4,20 +4,19 @@
 // (simple_mip_solver/nodes/base_node.py:273, :645-646).  Not a translation of anything: the
 // reference has no kernel.  Design:
 //
-//   * The condensed simplex tableau T (m x n, f64) lives in VGPRs for the whole solve: thread
-//     (bi, bj) of a TBI x TBJ thread grid owns T[bi + TBI*ii][bj + TBJ*jj], ii < R, jj < C.
-//     256x128 -> 16x32 threads x 8x8 doubles = 256 KiB of registers on one CU; it never touches
-//     HBM again after the initial coalesced read of A.
-//   * The interleaved ownership makes every LDS access of the per-pivot vectors (pivot row rho,
-//     pivot column alpha) conflict-free (consecutive lanes -> consecutive 8-byte words, or a
-//     half-wave broadcast), and lets work scale with ceil(m/TBI), ceil(n/TBJ).
-//   * Bounds by variable index and the nonbasic values live in LDS.
-//   * Row/column extraction uses wave-uniform (SGPR) local indices so register arrays are only
-//     ever indexed statically (no scratch).
-//   * The borders live in the registers of two owner waves (a column wave and a row wave, on
-//     different SIMDs); selections (leaving row, Harris ratio test) are single-wave DPP
-//     reductions by the owner, published through LDS mailbox words.  The next leaving row is
-//     picked while the other waves are still in the rank-1 update.
+//   * The condensed simplex tableau T (m x n, f64) lives in VGPRs for the whole solve: lane l of
+//     wave w owns T[w + NW*ii][l + 64*jj], ii < R, jj < C -- whole rows belong to one wave, a
+//     column to one lane position of every wave.  256x128 -> 8 waves x 64 lanes x 16x4 doubles =
+//     256 KiB of registers on one CU; it never touches HBM again after the initial coalesced read.
+//   * So the wave that holds the leaving row runs the ratio test straight from its registers, and
+//     every wave gets its part of the pivot column with v_readlane (into SGPRs, which feed the fma
+//     sweep as scalar operands): a pivot costs two workgroup barriers, not four.
+//   * The row border (beta0, basic values a + b*M, basic variable and its bounds) lives in the
+//     registers of the row wave, which picks the next leaving row while the other waves are
+//     still in the rank-1 update; it collects the pivot column through an LDS sequence counter
+//     instead of a barrier.  The column border (d, nonbasic variable/side) lives in LDS.
+//   * Register arrays are only ever indexed statically: dynamic rows/columns are reached through
+//     wave-uniform (SGPR) select chains (no scratch).
 //   * Arithmetic is IEEE f64 with explicit fma and true division, compiled with
 //     -ffp-contract=off, following the canonical operation order documented in
 //     oracle/mipx_oracle.c so results are bit-identical to the CPU oracle.
@@ -60,14 +59,15 @@ struct LpArgs {
     double *dbg_vec;    // [d (n) | beta0 (m) | ba (m) | bb (m)]
     int32_t *dbg_idx;   // [nvar (n) | bvar (m) | side (n)]
     int dbg_all;        // 0: node 0 only; 1: every node k at offsets k*m*n, k*(n+3m), k*(2n+m)
-    unsigned long long *prof;  // MIPX_KPROF builds only: per-section cycle totals of wave 0
+    unsigned long long *prof = nullptr;  // MIPX_KPROF builds only: per-section cycle totals of one wave
+    int prof_wave = 0;
 };
 
 #ifdef MIPX_KPROF
 #define KPROF_MARK(k)                                  \
     do {                                               \
         const unsigned long long t_ = clock64();       \
-        if (tid == 0) s.prof[k] += t_ - tprev;         \
+        if (tid == 64 * g.prof_wave) s.prof[k] += t_ - tprev; \
         tprev = t_;                                    \
     } while (0)
 #else
@@ -207,126 +207,213 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
-// value of lane ^ 16 (ds_swizzle bit mode: and 0x1f, xor 0x10)
+// value of lane ^ 16 / lane ^ 32
 __device__ __forceinline__ double swz16_f64(double v) {
-    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401f);
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401f);  // bit mode: and 0x1f, xor 0x10
     const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401f);
     return __hiloint2double(hi, lo);
 }
-// fold-in-half sum over the TBJ lanes that share a tableau row (valid in the lane with bj == 0):
-// the pairing (lane, lane + h), h = TBJ/2 .. 1, is the canonical summation tree
-template <int TBJ>
-__device__ __forceinline__ double fold_bj(double v) {
-    static_assert(TBJ == 16 || TBJ == 32, "row groups of 16 or 32 lanes");
-    if (TBJ == 32) v = v + swz16_f64(v);
-    v = v + dpp_f64<0x108, 0xf>(v);  // row_shl:8
-    v = v + dpp_f64<0x104, 0xf>(v);  // row_shl:4
-    v = v + dpp_f64<0x102, 0xf>(v);  // row_shl:2
-    v = v + dpp_f64<0x101, 0xf>(v);  // row_shl:1
-    return v;
+__device__ __forceinline__ double xor32_f64(double v) { return __shfl_xor(v, 32, 64); }
+// value of lane ^ 8 / ^ 4 / ^ 2 / ^ 1 on DPP (no LDS traffic)
+__device__ __forceinline__ double xor8_f64(double v) { return dpp_f64<0x128, 0xf>(v); }  // row_ror:8
+__device__ __forceinline__ double xor4_f64(double v) {
+    // banks 0,2 (lanes 0-3, 8-11 of a row) read lane + 4, banks 1,3 read lane - 4
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x104, 0xf, 0x5, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x104, 0xf, 0x5, false);
+    lo = __builtin_amdgcn_update_dpp(lo, __double2loint(v), 0x114, 0xf, 0xa, false);
+    hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(v), 0x114, 0xf, 0xa, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double xor2_f64(double v) { return dpp_f64<0x4e, 0xf>(v); }  // quad_perm [2,3,0,1]
+__device__ __forceinline__ double xor1_f64(double v) { return dpp_f64<0xb1, 0xf>(v); }  // quad_perm [1,0,3,2]
+// Row sums over the 64 lanes of a wave for RP rows at once (RP = 16 or 32 partial sums per lane in
+// arr_[]): a reduce-scatter whose levels pair (lane, lane ^ h), h = 32, 16, 8, ... -- the canonical
+// fold-in-half tree -- so that each exchange moves half as many values as the one before.  The sum
+// of row ROWSUM_ROW(lane) ends in arr_[0] of every lane.
+#define MIPX_ROWSUM_STEP(arr_, h_, dist_, xch_)                                             \
+    do {                                                                                    \
+        const bool up_ = (lane & (dist_)) != 0;                                             \
+        _Pragma("unroll") for (int k_ = 0; k_ < (h_); k_++) {                               \
+            const double send_ = up_ ? arr_[k_] : arr_[k_ + (h_)];                          \
+            const double keep_ = up_ ? arr_[k_ + (h_)] : arr_[k_];                          \
+            arr_[k_] = keep_ + xch_(send_);                                                 \
+        }                                                                                   \
+    } while (0)
+#define MIPX_ROWSUMS(arr_, rp_)                                                             \
+    do {                                                                                    \
+        if ((rp_) == 32) {                                                                  \
+            MIPX_ROWSUM_STEP(arr_, 16, 32, xor32_f64);                                      \
+            MIPX_ROWSUM_STEP(arr_, 8, 16, swz16_f64);                                       \
+            MIPX_ROWSUM_STEP(arr_, 4, 8, xor8_f64);                                         \
+            MIPX_ROWSUM_STEP(arr_, 2, 4, xor4_f64);                                         \
+            MIPX_ROWSUM_STEP(arr_, 1, 2, xor2_f64);                                         \
+            arr_[0] = arr_[0] + xor1_f64(arr_[0]);                                          \
+        } else {                                                                            \
+            MIPX_ROWSUM_STEP(arr_, 8, 32, xor32_f64);                                       \
+            MIPX_ROWSUM_STEP(arr_, 4, 16, swz16_f64);                                       \
+            MIPX_ROWSUM_STEP(arr_, 2, 8, xor8_f64);                                         \
+            MIPX_ROWSUM_STEP(arr_, 1, 4, xor4_f64);                                         \
+            arr_[0] = arr_[0] + xor2_f64(arr_[0]);                                          \
+            arr_[0] = arr_[0] + xor1_f64(arr_[0]);                                          \
+        }                                                                                   \
+    } while (0)
+// which row (local index ii) a lane holds after MIPX_ROWSUMS
+__device__ __forceinline__ int rowsum_row(int lane, int rp) {
+    const int r16 = ((lane & 32) ? 8 : 0) | ((lane & 16) ? 4 : 0) | ((lane & 8) ? 2 : 0) | ((lane & 4) ? 1 : 0);
+    return rp == 32 ? 2 * r16 + ((lane & 2) ? 1 : 0) : r16;
 }
 
-template <int MP, int NP>
+// mailboxes (one 16-byte LDS word each, so a reader needs a single ds_read_b128: the LDS pipe is
+// shared by all the waves of the workgroup and every DS instruction counts)
+struct alignas(16) MailA {  // row wave -> everybody
+    int win;     // refactor: leaving row or -1.  simplex: row | 0x8000 if sigma = -1 | cmd << 16
+    int lvmeta;  // leaving variable << 3 | fixed << 2 | side it goes to
+    double x;    // refactor: 1/p.  simplex: la (value a-part the leaving variable goes to)
+};
+struct alignas(16) MailB {  // ratio wave -> everybody
+    int q;       // entering column or -1
+    int ev;      // entering variable
+    double pinv;
+};
+struct alignas(16) MailC {  // ratio wave -> row wave, wave 0
+    int nfake, degen;  // nonbasic columns at the symbolic bound M; consecutive degenerate steps
+    double dq;
+    double vaq, vbq;
+};
+
+template <int NW, int R, int C>
 struct Smem {
-    double row[NP];       // extracted pivot row T[r][.]
-    double alpha[2][MP];  // extracted pivot column T[.][q] (double-buffered: the refactorisation
-                          // publishes the next column while the current one is still being read)
-    double lo[NP];        // structural bounds by variable index
+    static constexpr int MP = NW * R, NP = 64 * C;
+    double row[NP];     // pivot row T[r][.]
+    double alpha[NW * (R + 1)];  // pivot column, wave w's rows at [w*(R+1) ..): for the row wave
+    double lo[NP];      // structural bounds by variable index
     double up[NP];
-    double va[NP];        // nonbasic values a + b*M by column
+    double va[NP];      // nonbasic values a + b*M by column
     double vb[NP];
-    double d[NP];         // d, beta0, ba, bb, the basis lists and sides are staged here at setup and
-    double key[NP];       //   for the outputs; in between they live in their owners' registers
-    double beta0[MP];
-    double ba[MP];
+    double d[NP];       // reduced costs by column
+    double key[NP];     // x assembly
+    double beta0[MP];   // staging of the row border at setup / output (it lives in the row wave's
+    double ba[MP];      //   registers in between)
     double bb[MP];
+    MailA mbA;
+    MailB mbB;
+    MailC mbC;
     int bvar[MP];
-    int nvar[NP];
-    int side[NP];         // 0 lower, 1 upper, 2 fake upper
-    int wlist[NP];        // columns of the variables the warm start wants basic, ascending variable
+    int meta[NP];       // nonbasic variable << 3 | fixed << 2 | side (0 lower, 1 upper, 2 fake upper)
+    int nvar[NP];       // output staging
+    int side[NP];
+    int wlist[NP];      // columns of the variables the warm start wants basic, ascending variable
     int nw;
-    int ci[8];            // mailboxes: row wave / column wave -> everybody
-    double cd[4];
-    int pos[NP + MP];     // column of each variable in the starting tableau, -1 if basic
+    int seq;            // pivot columns published so far, one count per wave
+    int pos[NP + MP];   // column of each variable in the starting tableau, -1 if basic
     int8_t wantb[NP + MP];
     int8_t atup[NP + MP];
 #ifdef MIPX_KPROF
     unsigned long long prof[16];
 #endif
 };
-// mailbox words
-enum { kCmd = 0, kRow = 1, kLv = 2, kNewSide = 3, kCol = 4, kEv = 5, kFake = 6, kBland = 7 };
-enum { kPinv = 0, kLa = 1, kLb = 2 };
+// position of row i in Smem::alpha
+#define MIPX_AIDX(i_) (((i_) % NW) * (R + 1) + (i_) / NW)
+// wave-uniform reads of the mailboxes: one ds_read_b128 each, fields moved to scalar registers
+__device__ __forceinline__ void read_mail(const MailA &mb, int &win, int &lvmeta, double &x) {
+    const int4 v = *reinterpret_cast<const int4 *>(&mb);
+    win = __builtin_amdgcn_readfirstlane(v.x);
+    lvmeta = __builtin_amdgcn_readfirstlane(v.y);
+    x = __hiloint2double(__builtin_amdgcn_readfirstlane(v.w), __builtin_amdgcn_readfirstlane(v.z));
+}
+__device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, double &pinv) {
+    const int4 v = *reinterpret_cast<const int4 *>(&mb);
+    q = __builtin_amdgcn_readfirstlane(v.x);
+    ev = __builtin_amdgcn_readfirstlane(v.y);
+    pinv = __hiloint2double(__builtin_amdgcn_readfirstlane(v.w), __builtin_amdgcn_readfirstlane(v.z));
+}
+__device__ __forceinline__ void read_mail_counts(const MailC &mb, int &nfake, int &degen, double &dq) {
+    const int4 v = *reinterpret_cast<const int4 *>(&mb);
+    nfake = __builtin_amdgcn_readfirstlane(v.x);
+    degen = __builtin_amdgcn_readfirstlane(v.y);
+    dq = __hiloint2double(__builtin_amdgcn_readfirstlane(v.w), __builtin_amdgcn_readfirstlane(v.z));
+}
+__device__ __forceinline__ void read_mail_values(const MailC &mb, double &vaq, double &vbq) {
+    const int4 v = *reinterpret_cast<const int4 *>(&mb.vaq);
+    vaq = __hiloint2double(__builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.x));
+    vbq = __hiloint2double(__builtin_amdgcn_readfirstlane(v.w), __builtin_amdgcn_readfirstlane(v.z));
+}
 
 // ---- building blocks of the kernel body.  Macros, not lambdas: the register tableau T must be
 // seen as plain local arrays with static indices from the first optimisation pass on, or it is
 // demoted to scratch memory.
-// T[.][q] -> s.alpha[buf]
-#define MIPX_EXTRACT_COL(q_, buf_)                                                          \
-    do {                                                                                    \
-        const int qb_ = (q_) % TBJ, ql_ = (q_) / TBJ;                                       \
-        if (bj == qb_) {                                                                    \
-            _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == ql_) {               \
-                _Pragma("unroll") for (int ii = 0; ii < R; ii++)                            \
-                    s.alpha[buf_][bi + TBI * ii] = T[ii][jj];                               \
-            }                                                                               \
-        }                                                                                   \
-    } while (0)
-// T[r][.] -> s.row
-#define MIPX_EXTRACT_ROW(r_)                                                                \
-    do {                                                                                    \
-        const int rb_ = (r_) % TBI, rl_ = (r_) / TBI;                                       \
-        if (bi == rb_) {                                                                    \
-            _Pragma("unroll") for (int ii = 0; ii < R; ii++) if (ii == rl_) {               \
-                _Pragma("unroll") for (int jj = 0; jj < C; jj++)                            \
-                    s.row[bj + TBJ * jj] = T[ii][jj];                                       \
-            }                                                                               \
-        }                                                                                   \
-    } while (0)
-// rank-1 update of the register tableau; row r is in s.row, column q in s.alpha[buf].  Row r and
-// column q come out of the fma sweep as junk and are overwritten right after it.
-#define MIPX_UPDATE_T(r_, q_, pinv_, buf_)                                                  \
-    do {                                                                                    \
-        const int rb_ = (r_) % TBI, rl_ = (r_) / TBI;                                       \
-        const int qb_ = (q_) % TBJ, ql_ = (q_) / TBJ;                                       \
-        double al[R], rh[C];                                                                \
-        _Pragma("unroll") for (int ii = 0; ii < R; ii++) al[ii] = s.alpha[buf_][bi + TBI * ii]; \
-        _Pragma("unroll") for (int jj = 0; jj < C; jj++) rh[jj] = s.row[bj + TBJ * jj] * (pinv_); \
-        _Pragma("unroll") for (int ii = 0; ii < R; ii++) {                                  \
-            _Pragma("unroll") for (int jj = 0; jj < C; jj++)                                \
-                T[ii][jj] = fma(-al[ii], rh[jj], T[ii][jj]);                                \
-        }                                                                                   \
-        if (bj == qb_) { /* column q <- -alpha * (1/p) */                                   \
-            _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == ql_) {               \
-                _Pragma("unroll") for (int ii = 0; ii < R; ii++) T[ii][jj] = -al[ii] * (pinv_); \
-            }                                                                               \
-        }                                                                                   \
-        if (bi == rb_) { /* row r <- row * (1/p), and 1/p at the pivot position */          \
-            _Pragma("unroll") for (int ii = 0; ii < R; ii++) if (ii == rl_) {               \
-                _Pragma("unroll") for (int jj = 0; jj < C; jj++)                            \
-                    T[ii][jj] = (bj == qb_ && jj == ql_) ? (pinv_) : rh[jj];                \
-            }                                                                               \
-        }                                                                                   \
-    } while (0)
-// element k (wave-uniform) of a short register array: a select chain, no scratch
+// element k (wave-uniform) of a short register array: a select chain
 #define MIPX_PICK(dst_, arr_, n_, k_)                                                       \
     do {                                                                                    \
         dst_ = arr_[0];                                                                     \
         _Pragma("unroll") for (int t_ = 1; t_ < n_; t_++) dst_ = (k_) == t_ ? arr_[t_] : dst_; \
     } while (0)
-// the column wave's half of a pivot: d, and the variable that takes over column q
-#define MIPX_UPDATE_COLS(q_, pinv_, lv_, meta_)                                             \
+// this wave's part of column q: out of lane q % 64 with v_readlane into al[] (scalar registers,
+// they feed the fma sweep), then across lanes 0..R-1 with v_writelane and to s.alpha with ONE
+// ds_write (for the row wave), then one count on s.seq
+#define MIPX_PUBLISH_COL(q_)                                                                \
     do {                                                                                    \
-        double dq_;                                                                         \
-        MIPX_PICK(dq_, cD, PJ, (q_) >> 6);                                                  \
-        dq_ = readlane_f64(dq_, (q_)&63);                                                   \
-        _Pragma("unroll") for (int kk = 0; kk < PJ; kk++) {                                 \
+        const int qlane_ = (q_)&63, ql_ = (q_) >> 6;                                        \
+        _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == ql_) {                   \
+            _Pragma("unroll") for (int ii = 0; ii < R; ii++) al[ii] = readlane_f64(T[ii][jj], qlane_); \
+        }                                                                                   \
+        int plo_ = 0, phi_ = 0;                                                             \
+        _Pragma("unroll") for (int ii = 0; ii < R; ii++) {                                  \
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(plo_) : "s"(__double2loint(al[ii])), "n"(ii)); \
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(phi_) : "s"(__double2hiint(al[ii])), "n"(ii)); \
+        }                                                                                   \
+        if (lane < R) s.alpha[wave * (R + 1) + lane] = __hiloint2double(phi_, plo_);        \
+        if (lane == 0) __hip_atomic_fetch_add(&s.seq, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    } while (0)
+// the row wave waits until all NW parts of the current pivot column are in s.alpha
+#define MIPX_AWAIT_COL(target_)                                                             \
+    do {                                                                                    \
+        while (__hip_atomic_load(&s.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (target_)) \
+            __builtin_amdgcn_s_sleep(1);                                                    \
+    } while (0)
+// T[r][.] -> s.row (by the wave that holds row r)
+#define MIPX_EXTRACT_ROW(r_)                                                                \
+    do {                                                                                    \
+        const int rl_ = (r_) / NW;                                                          \
+        _Pragma("unroll") for (int ii = 0; ii < R; ii++) if (ii == rl_) {                   \
+            _Pragma("unroll") for (int jj = 0; jj < C; jj++) s.row[lane + 64 * jj] = T[ii][jj]; \
+        }                                                                                   \
+    } while (0)
+// rank-1 update of the register tableau for the pivot on (r, q): this wave's part of column q
+// is in al[] (MIPX_PUBLISH_COL), row r in s.row.  Row r and column q come out of the fma sweep as
+// junk and are overwritten right after it.
+#define MIPX_UPDATE_T(r_, q_, pinv_)                                                        \
+    do {                                                                                    \
+        const int rw_ = (r_) % NW, rl_ = (r_) / NW;                                         \
+        const int qlane_ = (q_)&63, ql_ = (q_) >> 6;                                        \
+        double rh[C];                                                                       \
+        _Pragma("unroll") for (int jj = 0; jj < C; jj++) rh[jj] = s.row[lane + 64 * jj] * (pinv_); \
+        _Pragma("unroll") for (int ii = 0; ii < R; ii++) {                                  \
+            _Pragma("unroll") for (int jj = 0; jj < C; jj++)                                \
+                T[ii][jj] = fma(-al[ii], rh[jj], T[ii][jj]);                                \
+        }                                                                                   \
+        if (lane == qlane_) { /* column q <- -alpha * (1/p) */                              \
+            _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == ql_) {               \
+                _Pragma("unroll") for (int ii = 0; ii < R; ii++) T[ii][jj] = -al[ii] * (pinv_); \
+            }                                                                               \
+        }                                                                                   \
+        if (wave == rw_) { /* row r <- row * (1/p), and 1/p at the pivot position */        \
+            _Pragma("unroll") for (int ii = 0; ii < R; ii++) if (ii == rl_) {               \
+                _Pragma("unroll") for (int jj = 0; jj < C; jj++)                            \
+                    T[ii][jj] = (lane == qlane_ && jj == ql_) ? (pinv_) : rh[jj];           \
+            }                                                                               \
+        }                                                                                   \
+    } while (0)
+// wave 0's half of a pivot: d, and the variable that takes over column q (borders in LDS)
+#define MIPX_UPDATE_COLS(q_, pinv_, dq_, lvmeta_)                                           \
+    do {                                                                                    \
+        _Pragma("unroll") for (int kk = 0; kk < C; kk++) {                                  \
             const int j = lane + 64 * kk;                                                   \
             const double rho_ = s.row[j] * (pinv_);                                         \
-            const double upd_ = fma(-dq_, rho_, cD[kk]);                                    \
-            cD[kk] = j == (q_) ? -dq_ * (pinv_) : upd_;                                     \
-            cM[kk] = j == (q_) ? (((lv_) << 3) | (meta_)) : cM[kk];                         \
+            const double upd_ = fma(-(dq_), rho_, s.d[j]);                                  \
+            s.d[j] = j == (q_) ? -(dq_) * (pinv_) : upd_;                                   \
         }                                                                                   \
+        if (lane == 0) s.meta[q_] = (lvmeta_);                                              \
     } while (0)
 
 // (a) the row wave's choice of the leaving row, or of the end of the solve, published for everybody:
@@ -410,41 +497,38 @@ _Pragma("unroll")                                                               
             if (!(win & 0x8000)) { la_ = lo; lb_ = 0.0; newside = 0; }                           \
             else if (!isinf(up)) { la_ = up; lb_ = 0.0; newside = 1; }                           \
             else { la_ = 0.0; lb_ = 1.0; newside = 2; }                                          \
+            (void)lb_;                                                                           \
             if (lane == 0) {                                                                     \
-                s.ci[kRow] = win;                                                                \
-                s.ci[kLv] = lvv;                                                                 \
-                s.ci[kNewSide] = newside | (lo == up ? 4 : 0);                                   \
-                s.cd[kLa] = la_;                                                                 \
-                s.cd[kLb] = lb_;                                                                 \
+                MailA mb_;                                                                       \
+                mb_.win = win & 0xffff;                                                                 \
+                mb_.lvmeta = (lvv << 3) | newside | (lo == up ? 4 : 0);                          \
+                mb_.x = la_;                                                                     \
+                s.mbA = mb_;                                                                     \
             }                                                                                    \
+        } else if (lane == 0) {                                                                  \
+            s.mbA.win = cmd << 16;                                                               \
         }                                                                                        \
-        if (lane == 0) s.ci[kCmd] = cmd;                                                         \
     } while (0)
 
-// Roles.  Every wave holds a slab of the tableau and takes part in the rank-1 update.  On top:
-//   * the column wave (wave 0) owns the column border -- reduced cost d_j, nonbasic variable, side,
-//     fixed flag -- in registers, NP/64 columns per lane, and runs the ratio test;
-//   * the row wave (wave 1; wave 0 on a single-wave tile) owns the row border -- beta0, the basic
-//     values a + b*M, the basic variable and its bounds -- and picks the leaving row.
-// They sit on different SIMDs and talk through LDS mailbox words; each hand-over costs one barrier.
-template <int TBI, int TBJ, int R, int C>
-__global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
-    constexpr int NT = TBI * TBJ;
-    constexpr int MP = TBI * R;
-    constexpr int NP = TBJ * C;
+// Roles.  Every wave holds whole rows of the tableau and takes part in the rank-1 update.  On top:
+//   * the row wave (wave 1; wave 0 on a single-wave tile) owns the row border in registers and
+//     picks the leaving row, as soon as it has the pivot column, while the others still update;
+//   * the wave that holds the leaving row runs the Harris ratio test on it;
+//   * wave 0 keeps the reduced costs (LDS) up to date.
+template <int NW, int R, int C>
+__global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
+    constexpr int NT = 64 * NW;
+    constexpr int MP = NW * R;
+    constexpr int NP = 64 * C;
     static_assert((NP & (NP - 1)) == 0, "padded column count must be a power of two");
-    static_assert(NT % 64 == 0 && NP % 64 == 0, "whole waves");
     constexpr int PI = (MP + 63) / 64;   // rows per lane of the row wave
-    constexpr int PJ = NP / 64;          // columns per lane of the column wave
-    constexpr int RW = NT > 64 ? 1 : 0;  // the row wave
-    __shared__ Smem<MP, NP> s;
+    constexpr int RW = NW > 1 ? 1 : 0;   // the row wave
+    __shared__ Smem<NW, R, C> s;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool isC = wave == 0, isR = wave == RW;
-    const int bi = tid / TBJ;
-    const int bj = tid % TBJ;
     const int m = g.m, n = g.n;
     const int nv = n + m;
     const double INF = __builtin_huge_val();
@@ -457,12 +541,13 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
     if (tid < 16) s.prof[tid] = 0;
     unsigned long long tprev = clock64();
 #endif
-    double T[R][C];
-    // border registers of the owner waves
-    double cD[PJ];  // reduced cost
-    int cM[PJ];     // nonbasic variable << 3 | fixed << 2 | side
+    double T[R][C];  // T[ii][jj] = tableau[wave + NW*ii][lane + 64*jj]
+    double al[R];    // this wave's part of the current pivot column (wave-uniform: scalar registers)
+#pragma unroll
+    for (int ii = 0; ii < R; ii++) al[ii] = 0.0;
+    // row border, in the registers of the row wave: row i = lane + 64*kk
     double rB0[PI], rBa[PI], rBb[PI], rLo[PI], rUp[PI];
-    int rM[PI];     // basic variable << 2 | pivoted by the refactorisation << 1 | wanted basic
+    int rM[PI];      // basic variable << 2 | pivoted by the refactorisation << 1 | wanted basic
     const size_t src = g.slot ? (size_t)g.slot[node] : (size_t)node;
     const double *gA = g.A + (size_t)node * g.A_stride;
     const double *gb = g.b + (size_t)node * g.b_stride;
@@ -475,15 +560,15 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
     const bool anchored = g.anchor_T != nullptr && vin != nullptr;
     const double sgn = anchored ? 1.0 : -1.0;
     {
-        // every load is issued unconditionally from a clamped address (64 independent requests in
-        // flight); the padding is zeroed afterwards
+        // every load is issued unconditionally from a clamped address (all requests in flight at
+        // once, 512 contiguous bytes per wave instruction); the padding is zeroed afterwards
         const double *tsrc = anchored ? g.anchor_T : gA;
         int joff[C];
 #pragma unroll
-        for (int jj = 0; jj < C; jj++) joff[jj] = min(bj + TBJ * jj, n - 1);
+        for (int jj = 0; jj < C; jj++) joff[jj] = min(lane + 64 * jj, n - 1);
 #pragma unroll
         for (int ii = 0; ii < R; ii++) {
-            const double *arow = tsrc + (size_t)min(bi + TBI * ii, m > 0 ? m - 1 : 0) * n;
+            const double *arow = tsrc + (size_t)min(wave + NW * ii, m > 0 ? m - 1 : 0) * n;
 #pragma unroll
             for (int jj = 0; jj < C; jj++) T[ii][jj] = m > 0 ? arow[joff[jj]] : 0.0;
         }
@@ -491,7 +576,7 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
         for (int ii = 0; ii < R; ii++) {
 #pragma unroll
             for (int jj = 0; jj < C; jj++)
-                T[ii][jj] = (bi + TBI * ii < m && bj + TBJ * jj < n) ? sgn * T[ii][jj] : 0.0;
+                T[ii][jj] = (wave + NW * ii < m && lane + 64 * jj < n) ? sgn * T[ii][jj] : 0.0;
         }
     }
 #pragma unroll 1
@@ -515,8 +600,14 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
         s.atup[v] = st == 2;
         s.pos[v] = -1;
     }
+    if (tid == 0) s.seq = 0;
     __syncthreads();
-    for (int j = tid; j < n; j += NT) s.pos[s.nvar[j]] = j;
+    for (int j = tid; j < NP; j += NT) {
+        const int v = s.nvar[j];
+        if (j < n) s.pos[v] = j;
+        const bool fix = j < n && v < n && s.lo[v < n && v >= 0 ? v : 0] == s.up[v < n && v >= 0 ? v : 0];
+        s.meta[j] = (v << 3) | (fix ? 4 : 0);
+    }
     __syncthreads();
     if (tid < 64) {  // columns of the variables to pivot in, in ascending variable order
         int cnt = 0;
@@ -529,21 +620,13 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
         }
         if (lane == 0) s.nw = cnt;
     }
-    // the owners take their borders into registers
-#pragma unroll
-    for (int kk = 0; kk < PJ; kk++) {
-        const int j = lane + 64 * kk;
-        const int v = s.nvar[j];
-        cD[kk] = s.d[j];
-        const bool fix = v >= 0 && v < n && s.lo[v < 0 ? 0 : (v < n ? v : 0)] == s.up[v < 0 ? 0 : (v < n ? v : 0)];
-        cM[kk] = (v << 3) | (fix ? 4 : 0);
-    }
+    // the row wave takes its border into registers
 #pragma unroll
     for (int kk = 0; kk < PI; kk++) {
         const int i = lane + 64 * kk;
-        const int v = i < MP ? s.bvar[i] : -1;
+        const int v = i < MP ? s.bvar[i < MP ? i : 0] : -1;
         const bool st = v >= 0 && v < n;
-        rB0[kk] = i < MP ? s.beta0[i] : 0.0;
+        rB0[kk] = i < MP ? s.beta0[i < MP ? i : 0] : 0.0;
         rBa[kk] = 0.0;
         rBb[kk] = 0.0;
         rLo[kk] = st ? s.lo[st ? v : 0] : 0.0;
@@ -555,36 +638,34 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
 
     int npiv = 0, iters = 0, status = -1;
     const int cap = 100 * (m + n) + 1000;
-    int ab = 0;     // alpha buffer in use
-    int degen = 0;  // consecutive degenerate steps (column wave); > m+n -> Bland's rule
-    int nfake = 0;  // nonbasic columns at the symbolic bound M (column wave)
+    int cols = 0;  // pivot columns published so far (the row wave waits for NW * cols counts)
     KPROF_MARK(15);
 
     // ---- 1. refactor: pivot the wanted variables into the basis, ascending variable -----------
+    // Per pivot: every wave publishes its part of column q (after its own update of the previous
+    // pivot); the row wave picks the row; barrier; the wave holding row r publishes it; barrier;
+    // rank-1 update.  The row wave's choice overlaps the other waves' update.
     if (vin) {
-        if (nw > 0) MIPX_EXTRACT_COL(__builtin_amdgcn_readfirstlane(s.wlist[0]), 0);
-        __syncthreads();
+        if (nw > 0) {
+            MIPX_PUBLISH_COL(__builtin_amdgcn_readfirstlane(s.wlist[0]));
+            cols++;
+        }
         KPROF_MARK(8);
         for (int w = 0; w < nw;) {
             const int q = __builtin_amdgcn_readfirstlane(s.wlist[w]);
-            if (isC) {  // the entering variable, for the row wave
-                int cm;
-                MIPX_PICK(cm, cM, PJ, q >> 6);
-                const int ev = __builtin_amdgcn_readlane(cm, q & 63) >> 3;
-                if (lane == 0) s.ci[kEv] = ev;
-            }
             if (isR) {  // leaving row: largest |T_iq| among rows whose basic variable is not wanted
+                MIPX_AWAIT_COL(NW * cols);
                 double k1 = -1.0, k2 = -1.0;  // (fallback: wanted, but not pivoted in yet)
                 int p1 = kNoCand, p2 = kNoCand;
-                double rc[PI];
+                double rc[PI], av[PI];
 #pragma unroll
                 for (int kk = 0; kk < PI; kk++) {
                     const int i = lane + 64 * kk;
-                    const double av = i < MP ? s.alpha[ab][i < MP ? i : 0] : 0.0;
-                    const double a = fabs(av);
+                    av[kk] = i < MP ? s.alpha[MIPX_AIDX(i < MP ? i : 0)] : 0.0;
+                    const double a = fabs(av[kk]);
                     const bool ok = i < m && a > kPivTol;
                     const bool wanted = rM[kk] & 1, ent = rM[kk] & 2;
-                    rc[kk] = 1.0 / av;  // 1/p of every candidate, off the selection's critical path
+                    rc[kk] = 1.0 / av[kk];  // 1/p of every candidate, off the selection's critical path
                     keep_max(k1, p1, a, i, ok & !wanted);
                     keep_max(k2, p2, a, i, ok & wanted & !ent);
                 }
@@ -592,131 +673,153 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                 int rr = wave_argmax_pos(k1, p1, km);
                 if (rr == kNoCand) rr = wave_argmax_pos(k2, p2, km);
                 if (rr != kNoCand) {
-                    double rcv;
+                    double rcv, b0r;
                     int rmv;
                     MIPX_PICK(rcv, rc, PI, rr >> 6);
                     MIPX_PICK(rmv, rM, PI, rr >> 6);
+                    MIPX_PICK(b0r, rB0, PI, rr >> 6);
                     const double pinv = readlane_f64(rcv, rr & 63);
                     const int lv = __builtin_amdgcn_readlane(rmv, rr & 63) >> 2;
                     const bool fix = lv < n && s.lo[lv < n ? lv : 0] == s.up[lv < n ? lv : 0];
                     if (lane == 0) {
-                        s.ci[kRow] = rr;
-                        s.ci[kLv] = lv;
-                        s.ci[kNewSide] = fix ? 4 : 0;
-                        s.cd[kPinv] = pinv;
+                        MailA mb;
+                        mb.win = rr;
+                        mb.lvmeta = (lv << 3) | (fix ? 4 : 0);
+                        mb.x = pinv;
+                        s.mbA = mb;
                     }
-                } else if (lane == 0) {
-                    s.ci[kRow] = -1;
-                }
-            }
-            __syncthreads();
-            KPROF_MARK(9);
-            const int r = __builtin_amdgcn_readfirstlane(s.ci[kRow]);
-            w++;
-            const int qn = w < nw ? __builtin_amdgcn_readfirstlane(s.wlist[w < nw ? w : 0]) : -1;
-            // (a singular column -- no usable pivot row -- stays nonbasic: both halves are skipped)
-            const double pinv = uniform_f64(s.cd[kPinv]);
-            const int lv = __builtin_amdgcn_readfirstlane(s.ci[kLv]);
-            const int meta = __builtin_amdgcn_readfirstlane(s.ci[kNewSide]);
-            const int ev = __builtin_amdgcn_readfirstlane(s.ci[kEv]);
-            if (r >= 0) MIPX_EXTRACT_ROW(r);
-            __syncthreads();
-            KPROF_MARK(10);
-            if (r >= 0) {
-                if (isR) {
-                    double b0r;
-                    MIPX_PICK(b0r, rB0, PI, r >> 6);
-                    const double rhon = readlane_f64(b0r, r & 63) * pinv;
+                    // beta0 and the basis list, right away
+                    const int ev = __builtin_amdgcn_readfirstlane(s.meta[q]) >> 3;
+                    const double rhon = readlane_f64(b0r, rr & 63) * pinv;
                     const double elo = ev < n ? s.lo[ev < n ? ev : 0] : 0.0;
                     const double eup = ev < n ? s.up[ev < n ? ev : 0] : INF;
                     const int em = (ev << 2) | 2 | (s.wantb[ev] ? 1 : 0);
 #pragma unroll
                     for (int kk = 0; kk < PI; kk++) {
-                        const int i = lane + 64 * kk;
-                        const double a = i < MP ? s.alpha[ab][i < MP ? i : 0] : 0.0;
-                        const bool pr = i == r;
-                        rB0[kk] = pr ? rhon : fma(-a, rhon, rB0[kk]);
+                        const bool pr = lane + 64 * kk == rr;
+                        const double upd = fma(-av[kk], rhon, rB0[kk]);
+                        rB0[kk] = pr ? rhon : upd;
                         rM[kk] = pr ? em : rM[kk];
                         rLo[kk] = pr ? elo : rLo[kk];
                         rUp[kk] = pr ? eup : rUp[kk];
                     }
+                } else if (lane == 0) {
+                    s.mbA.win = -1;  // singular: the variable stays nonbasic
                 }
-                if (isC) MIPX_UPDATE_COLS(q, pinv, lv, meta);
-                MIPX_UPDATE_T(r, q, pinv, ab);
+            }
+            __syncthreads();
+            KPROF_MARK(9);
+            int r, lvmeta;
+            double pinv;
+            read_mail(s.mbA, r, lvmeta, pinv);
+            if (r >= 0 && wave == r % NW) MIPX_EXTRACT_ROW(r);
+            __syncthreads();
+            KPROF_MARK(10);
+            if (r >= 0) {
+                if (isC) {
+                    const double dq = uniform_f64(s.d[q]);
+                    MIPX_UPDATE_COLS(q, pinv, dq, lvmeta);
+                }
+                KPROF_MARK(12);
+                MIPX_UPDATE_T(r, q, pinv);
+                KPROF_MARK(13);
                 npiv++;
             }
-            if (qn >= 0) MIPX_EXTRACT_COL(qn, ab ^ 1);  // next column, from registers already updated
-            ab ^= 1;
-            __syncthreads();
-            KPROF_MARK(11);
+            w++;
+            if (w < nw) {  // next column, from registers already updated
+                MIPX_PUBLISH_COL(__builtin_amdgcn_readfirstlane(s.wlist[w < nw ? w : 0]));
+                cols++;
+            }
+            KPROF_MARK(14);
         }
+        __syncthreads();
+        KPROF_MARK(11);
     }
 
     if (!(vin && g.refactor_only)) {
-        // ---- 2. nonbasic sides and values (column wave), then the basic values ----------------
+        // ---- 2. nonbasic sides and values (wave 0), then the basic values ---------------------
         if (isC) {
             int fakes = 0;
 #pragma unroll
-            for (int kk = 0; kk < PJ; kk++) {
+            for (int kk = 0; kk < C; kk++) {
                 const int j = lane + 64 * kk;
                 int side = 0;
                 if (j < n) {
-                    const int v = cM[kk] >> 3;
+                    const int mt = s.meta[j];
+                    const int v = mt >> 3;
                     const double lo = v < n ? s.lo[v < n ? v : 0] : 0.0;
                     const double up = v < n ? s.up[v < n ? v : 0] : INF;
-                    const double dj = cD[kk];
+                    const double dj = s.d[j];
                     if (lo == up) side = 0;
                     else if (dj < -kDTol) side = isinf(up) ? 2 : 1;
                     else if (dj > kDTol) side = 0;
                     else side = (s.atup[v] && !isinf(up)) ? 1 : 0;
                     s.va[j] = side == 0 ? lo : side == 1 ? up : 0.0;
                     s.vb[j] = side == 2 ? 1.0 : 0.0;
+                    s.meta[j] = (mt & ~3) | side;
                 }
-                cM[kk] = (cM[kk] & ~3) | side;
                 fakes += __popcll(__ballot(side == 2));
             }
-            nfake = fakes;
-            if (lane == 0) s.ci[kFake] = fakes;
+            if (lane == 0) {
+                s.mbC.nfake = fakes;
+                s.mbC.degen = 0;
+            }
         }
         __syncthreads();
-        int nfk = __builtin_amdgcn_readfirstlane(s.ci[kFake]);
+        int nfk = __builtin_amdgcn_readfirstlane(s.mbC.nfake);
         {
+            constexpr int RP = R <= 16 ? 16 : 32;
             double va[C], vb[C];
 #pragma unroll
             for (int jj = 0; jj < C; jj++) {
-                va[jj] = s.va[bj + TBJ * jj];
-                vb[jj] = s.vb[bj + TBJ * jj];
+                va[jj] = s.va[lane + 64 * jj];
+                vb[jj] = s.vb[lane + 64 * jj];
             }
+            double pa[RP], pb[RP];
 #pragma unroll
-            for (int ii = 0; ii < R; ii++) {
-                double pa[C];
+            for (int ii = 0; ii < RP; ii++) {
+                double t[C];
 #pragma unroll
-                for (int jj = 0; jj < C; jj++) pa[jj] = T[ii][jj] * va[jj];
+                for (int jj = 0; jj < C; jj++) t[jj] = ii < R ? T[ii < R ? ii : 0][jj] * va[jj] : 0.0;
 #pragma unroll
                 for (int h = C / 2; h >= 1; h >>= 1) {
 #pragma unroll
-                    for (int jj = 0; jj < h; jj++) pa[jj] = pa[jj] + pa[jj + h];
+                    for (int jj = 0; jj < h; jj++) t[jj] = t[jj] + t[jj + h];
                 }
-                const double sa = fold_bj<TBJ>(pa[0]);
-                double sb = 0.0;
-                if (nfk != 0) {  // the M parts: all zero unless some nonbasic sits at the symbolic bound
-                    double pb[C];
+                pa[ii] = t[0];
+                pb[ii] = 0.0;
+            }
+            MIPX_ROWSUMS(pa, RP);
+            if (nfk != 0) {  // the M parts: all zero unless some nonbasic sits at the symbolic bound
 #pragma unroll
-                    for (int jj = 0; jj < C; jj++) pb[jj] = T[ii][jj] * vb[jj];
+                for (int ii = 0; ii < RP; ii++) {
+                    double t[C];
+#pragma unroll
+                    for (int jj = 0; jj < C; jj++) t[jj] = ii < R ? T[ii < R ? ii : 0][jj] * vb[jj] : 0.0;
 #pragma unroll
                     for (int h = C / 2; h >= 1; h >>= 1) {
 #pragma unroll
-                        for (int jj = 0; jj < h; jj++) pb[jj] = pb[jj] + pb[jj + h];
+                        for (int jj = 0; jj < h; jj++) t[jj] = t[jj] + t[jj + h];
                     }
-                    sb = fold_bj<TBJ>(pb[0]);
+                    pb[ii] = t[0];
                 }
-                if (bj == 0) {
-                    s.ba[bi + TBI * ii] = sa;
-                    s.bb[bi + TBI * ii] = 0.0 - sb;
-                }
+                MIPX_ROWSUMS(pb, RP);
+            }
+            const int ii = rowsum_row(lane, RP);
+            if ((lane & (RP == 32 ? 1 : 3)) == 0 && ii < R) {
+                s.ba[wave + NW * ii] = pa[0];
+                s.bb[wave + NW * ii] = 0.0 - pb[0];
             }
         }
         __syncthreads();
+        KPROF_MARK(7);
+
+        // ---- 3. dual simplex ------------------------------------------------------------------
+        // The row wave picks the leaving row r; barrier; the wave holding row r publishes it and
+        // runs the ratio test; barrier; every wave publishes its part of column q and updates its
+        // rows, the row wave going through the border update and the next choice first.
+        bool bland = false;
+        double sel_b0 = 0.0, sel_ba = 0.0, sel_bb = 0.0;  // border values of row r (row wave)
         if (isR) {
 #pragma unroll
             for (int kk = 0; kk < PI; kk++) {
@@ -724,120 +827,140 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                 rBa[kk] = i < MP ? rB0[kk] - s.ba[i < MP ? i : 0] : 0.0;
                 rBb[kk] = i < MP ? s.bb[i < MP ? i : 0] : 0.0;
             }
+            MIPX_LEAVE_SELECT();
         }
-        KPROF_MARK(7);
-
-        // ---- 3. dual simplex ------------------------------------------------------------------
-        // The row wave picks the leaving row; row r is published; the column wave runs the ratio
-        // test; column q is published; then the pivot: borders by their owners -- the row wave goes
-        // straight on to the next leaving row -- and the tableau by everybody.
-        bool bland = false;
-        int r = 0, q = 0, sigma = 1, lv = 0, meta = 0, ev = 0;
-        double la = 0.0, lb = 0.0, pinv = 0.0, vaq = 0.0, vbq = 0.0;
-        double sel_b0 = 0.0, sel_ba = 0.0, sel_bb = 0.0;  // border values of row r (row wave)
-        if (isR) MIPX_LEAVE_SELECT();
         __syncthreads();
         for (;;) {
-            {
-                const int cmd = __builtin_amdgcn_readfirstlane(s.ci[kCmd]);
-                if (cmd) { status = cmd == 1 ? 0 : cmd == 3 ? 2 : 3; break; }
-                const int win = __builtin_amdgcn_readfirstlane(s.ci[kRow]);
-                r = win & 0x7fff;
-                sigma = (win & 0x8000) ? -1 : 1;
-                lv = __builtin_amdgcn_readfirstlane(s.ci[kLv]);
-                meta = __builtin_amdgcn_readfirstlane(s.ci[kNewSide]);
-                la = uniform_f64(s.cd[kLa]);
-                lb = uniform_f64(s.cd[kLb]);
-            }
-            MIPX_EXTRACT_ROW(r);  // (b)
-            __syncthreads();
+            int win, lvmeta;
+            double la;
+            read_mail(s.mbA, win, lvmeta, la);
+            const int cmd = win >> 16;
+            if (cmd) { status = cmd == 1 ? 0 : cmd == 3 ? 2 : 3; break; }
+            const int r = win & 0x7fff;
+            const double lb = (lvmeta & 3) == 2 ? 1.0 : 0.0;
             KPROF_MARK(1);
-            if (isC) {  // (c) Harris ratio test on row r
-                double aa[PJ], dje[PJ], rc[PJ];
-                bool el[PJ];
+            if (wave == r % NW) {  // (b, c) row r, and the Harris ratio test on it
+                const unsigned sflip = (win & 0x8000) ? 0x80000000u : 0u;  // sigma = -1
+                int nfake, degen;
+                double dq_unused;
+                read_mail_counts(s.mbC, nfake, degen, dq_unused);
+                const bool bl = degen > m + n;
+                double rv[C];
+                const int rl = r / NW;
+#pragma unroll
+                for (int jj = 0; jj < C; jj++) rv[jj] = 0.0;
+#pragma unroll
+                for (int ii = 0; ii < R; ii++)
+                    if (ii == rl) {
+#pragma unroll
+                        for (int jj = 0; jj < C; jj++) rv[jj] = T[ii][jj];
+                    }
+#pragma unroll
+                for (int jj = 0; jj < C; jj++) s.row[lane + 64 * jj] = rv[jj];
+                double aa[C], dje[C], rc[C], dd[C];
+                int mt[C];
+                bool el[C];
                 double k1 = INF;
                 int p1 = kNoCand;
-                const double tol = bland ? 0.0 : kDTol;  // Bland: the textbook ratio dj / |a|
+                const double tol = bl ? 0.0 : kDTol;  // Bland: the textbook ratio dj / |a|
 #pragma unroll
-                for (int kk = 0; kk < PJ; kk++) {
+                for (int kk = 0; kk < C; kk++) {
+                    dd[kk] = s.d[lane + 64 * kk];
+                    mt[kk] = s.meta[lane + 64 * kk];
+                }
+#pragma unroll
+                for (int kk = 0; kk < C; kk++) {
                     const int j = lane + 64 * kk;
-                    const double rv = s.row[j];
-                    const double a = sigma < 0 ? -rv : rv;
-                    const int sd = cM[kk] & 3;
-                    el[kk] = ((cM[kk] & 4) == 0) & (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
-                    dje[kk] = sd == 0 ? fmax(cD[kk], 0.0) : fmax(-cD[kk], 0.0);
+                    const double a = __hiloint2double(__double2hiint(rv[kk]) ^ sflip, __double2loint(rv[kk]));
+                    const int sd = mt[kk] & 3;
+                    el[kk] = ((mt[kk] & 4) == 0) & (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
+                    dje[kk] = sd == 0 ? fmax(dd[kk], 0.0) : fmax(-dd[kk], 0.0);
                     aa[kk] = fabs(a);
                     const double key = (dje[kk] + tol) / aa[kk];  // unconditionally: no divergent branch
-                    rc[kk] = 1.0 / rv;                            // 1/p of every candidate, likewise
-                    keep_min(k1, p1, key, ((cM[kk] >> 3) << 16) | j, el[kk]);
+                    rc[kk] = 1.0 / rv[kk];                        // 1/p of every candidate, likewise
+                    keep_min(k1, p1, key, ((mt[kk] >> 3) << 16) | j, el[kk]);
                 }
                 double thmax;
                 const int w1 = wave_argmin_pos(k1, p1, thmax);
                 int qq = -1;
-                if (w1 != kNoCand && bland) {
+                if (w1 != kNoCand && bl) {
                     qq = w1 & 0xffff;  // ties -> lowest variable index
                 } else if (w1 != kNoCand) {
                     const int jmin = w1 & 0xffff;
                     double k2 = -1.0;
                     int p2 = kNoCand;
 #pragma unroll
-                    for (int kk = 0; kk < PJ; kk++) {
+                    for (int kk = 0; kk < C; kk++) {
                         const int j = lane + 64 * kk;
                         const bool ok = el[kk] & ((j == jmin) | !(dje[kk] > thmax * aa[kk]));
-                        keep_max(k2, p2, aa[kk], ((cM[kk] >> 3) << 16) | j, ok);
+                        keep_max(k2, p2, aa[kk], ((mt[kk] >> 3) << 16) | j, ok);
                     }
                     double amax;
                     qq = wave_argmax_pos(k2, p2, amax) & 0xffff;
                 }
                 if (qq >= 0) {
                     const int ql = qq & 63, qk = qq >> 6;
-                    double t0, t1;
+                    double t0, t1, t2;
                     int tm;
-                    MIPX_PICK(t0, dje, PJ, qk);
-                    MIPX_PICK(t1, rc, PJ, qk);
-                    MIPX_PICK(tm, cM, PJ, qk);
+                    MIPX_PICK(t0, dje, C, qk);
+                    MIPX_PICK(t1, rc, C, qk);
+                    MIPX_PICK(t2, dd, C, qk);
+                    MIPX_PICK(tm, mt, C, qk);
                     const double djq = readlane_f64(t0, ql);
-                    degen = djq <= kDTol ? degen + 1 : 0;
                     const int cm = __builtin_amdgcn_readlane(tm, ql);
-                    nfake += ((meta & 3) == 2 ? 1 : 0) - ((cm & 3) == 2 ? 1 : 0);
-                    const double pv = readlane_f64(t1, ql);
+                    degen = djq <= kDTol ? degen + 1 : 0;
+                    nfake += ((lvmeta & 3) == 2 ? 1 : 0) - ((cm & 3) == 2 ? 1 : 0);
+                    const double pv = readlane_f64(t1, ql), dq = readlane_f64(t2, ql);
+                    const double vaq = s.va[qq], vbq = s.vb[qq];
                     if (lane == 0) {
-                        s.ci[kEv] = cm >> 3;
-                        s.ci[kFake] = nfake;
-                        s.ci[kBland] = degen > m + n;
-                        s.cd[kPinv] = pv;
+                        MailB mb;
+                        mb.q = qq;
+                        mb.ev = cm >> 3;
+                        mb.pinv = pv;
+                        s.mbB = mb;
+                        MailC mc;
+                        mc.nfake = nfake;
+                        mc.degen = degen;
+                        mc.dq = dq;
+                        mc.vaq = vaq;
+                        mc.vbq = vbq;
+                        s.mbC = mc;
                     }
+                } else if (lane == 0) {
+                    s.mbB.q = -1;
                 }
-                if (lane == 0) s.ci[kCol] = qq;
             }
             __syncthreads();
             KPROF_MARK(3);
-            q = __builtin_amdgcn_readfirstlane(s.ci[kCol]);
+            int q, ev;
+            double pinv;
+            read_mail(s.mbB, q, ev, pinv);
             if (q < 0) { status = 1; break; }  // no entering column: primal infeasible
-            pinv = uniform_f64(s.cd[kPinv]);
-            ev = __builtin_amdgcn_readfirstlane(s.ci[kEv]);
-            nfk = __builtin_amdgcn_readfirstlane(s.ci[kFake]);
-            bland = __builtin_amdgcn_readfirstlane(s.ci[kBland]) != 0;
-            vaq = uniform_f64(s.va[q]);
-            vbq = uniform_f64(s.vb[q]);
-            MIPX_EXTRACT_COL(q, ab);  // (d)
-            __syncthreads();
-            KPROF_MARK(4);
+            MIPX_PUBLISH_COL(q);  // (d)
+            cols++;
             iters++;
             npiv++;
+            KPROF_MARK(4);
             if (isR) {  // basic values after the pivot on (r, q), then the next leaving row
+                int dg;
+                double dq_unused, vaq, vbq;
+                read_mail_counts(s.mbC, nfk, dg, dq_unused);
+                read_mail_values(s.mbC, vaq, vbq);
+                bland = dg > m + n;
                 const double rhon = sel_b0 * pinv;
                 const double ta = (sel_ba - la) * pinv, tb = (sel_bb - lb) * pinv;
                 const double elo = ev < n ? s.lo[ev < n ? ev : 0] : 0.0;
                 const double eup = ev < n ? s.up[ev < n ? ev : 0] : INF;
+                MIPX_AWAIT_COL(NW * cols);
 #pragma unroll
                 for (int kk = 0; kk < PI; kk++) {
                     const int i = lane + 64 * kk;
-                    const double a = i < MP ? s.alpha[ab][i < MP ? i : 0] : 0.0;
+                    const double a = i < MP ? s.alpha[MIPX_AIDX(i < MP ? i : 0)] : 0.0;
                     const bool pr = i == r;
-                    rB0[kk] = pr ? rhon : fma(-a, rhon, rB0[kk]);
-                    rBa[kk] = pr ? vaq + ta : fma(-a, ta, rBa[kk]);
-                    rBb[kk] = pr ? vbq + tb : fma(-a, tb, rBb[kk]);
+                    const double u0 = fma(-a, rhon, rB0[kk]), u1 = fma(-a, ta, rBa[kk]), u2 = fma(-a, tb, rBb[kk]);
+                    rB0[kk] = pr ? rhon : u0;
+                    rBa[kk] = pr ? vaq + ta : u1;
+                    rBb[kk] = pr ? vbq + tb : u2;
                     rM[kk] = pr ? (ev << 2) : rM[kk];
                     rLo[kk] = pr ? elo : rLo[kk];
                     rUp[kk] = pr ? eup : rUp[kk];
@@ -845,10 +968,15 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
                 MIPX_LEAVE_SELECT();
             }
             if (isC) {
-                MIPX_UPDATE_COLS(q, pinv, lv, meta);
+                int nf_, dg_;
+                double dq;
+                read_mail_counts(s.mbC, nf_, dg_, dq);
+                MIPX_UPDATE_COLS(q, pinv, dq, lvmeta);
                 if (lane == 0) { s.va[q] = la; s.vb[q] = lb; }
             }
-            MIPX_UPDATE_T(r, q, pinv, ab);
+            KPROF_MARK(2);
+            MIPX_UPDATE_T(r, q, pinv);
+            KPROF_MARK(5);
             __syncthreads();
             KPROF_MARK(0);
         }
@@ -856,26 +984,20 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
         status = 3;
     }
 
-
     // ---- 4. outputs ---------------------------------------------------------------------------
 #ifdef MIPX_KPROF
     KPROF_MARK(6);
+    __syncthreads();
     if (g.prof && tid == 0) {
-        for (int k = 0; k < 12; k++) atomicAdd(&g.prof[k], s.prof[k]);
-        atomicAdd(&g.prof[12], (unsigned long long)iters);
-        atomicAdd(&g.prof[13], (unsigned long long)(npiv - iters));
-        atomicAdd(&g.prof[14], 1ull);
-        atomicAdd(&g.prof[15], s.prof[15]);
+        for (int k = 0; k < 16; k++) atomicAdd(&g.prof[k], s.prof[k]);
+        atomicAdd(&g.prof[16], (unsigned long long)iters);
+        atomicAdd(&g.prof[17], (unsigned long long)(npiv - iters));
+        atomicAdd(&g.prof[18], 1ull);
     }
 #endif
-    if (isC) {
-#pragma unroll
-        for (int kk = 0; kk < PJ; kk++) {
-            const int j = lane + 64 * kk;
-            s.d[j] = cD[kk];
-            s.nvar[j] = cM[kk] >> 3;
-            s.side[j] = cM[kk] & 3;
-        }
+    for (int j = tid; j < NP; j += NT) {
+        s.nvar[j] = s.meta[j] >> 3;
+        s.side[j] = s.meta[j] & 3;
     }
     if (isR) {
 #pragma unroll
@@ -923,7 +1045,7 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
         for (int ii = 0; ii < R; ii++) {
 #pragma unroll
             for (int jj = 0; jj < C; jj++) {
-                const int i = bi + TBI * ii, j = bj + TBJ * jj;
+                const int i = wave + NW * ii, j = lane + 64 * jj;
                 if (i < m && j < n) dT[(size_t)i * n + j] = T[ii][jj];
             }
         }
@@ -966,11 +1088,15 @@ __global__ __launch_bounds__(TBI *TBJ) void lp_dual_simplex(LpArgs g) {
     __syncthreads();
 }
 
-#undef MIPX_EXTRACT_COL
+#undef MIPX_PUBLISH_COL
+#undef MIPX_AWAIT_COL
 #undef MIPX_EXTRACT_ROW
 #undef MIPX_UPDATE_T
 #undef MIPX_UPDATE_COLS
 #undef MIPX_PICK
+#undef MIPX_ROWSUMS
+#undef MIPX_ROWSUM_STEP
+#undef MIPX_AIDX
 #undef MIPX_LEAVE_SELECT
 
 }  // namespace mipx

@@ -65,17 +65,18 @@ struct KernelCfg {
     void (*launch)(const mipx::LpArgs &, int grid, hipStream_t);
 };
 
-template <int TBI, int TBJ, int R, int C>
+template <int NW, int R, int C>
 void launch_cfg(const mipx::LpArgs &a, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((mipx::lp_dual_simplex<TBI, TBJ, R, C>), dim3(grid), dim3(TBI * TBJ), 0, st, a);
+    hipLaunchKernelGGL((mipx::lp_dual_simplex<NW, R, C>), dim3(grid), dim3(64 * NW), 0, st, a);
 }
 
 // ordered by on-chip footprint; the first that fits (m <= mp, n <= np) is used
 const KernelCfg kCfgs[] = {
-    {32, 64, 64, "lp_dual_simplex<4,16,8,4>", launch_cfg<4, 16, 8, 4>},
-    {64, 128, 256, "lp_dual_simplex<8,32,8,4>", launch_cfg<8, 32, 8, 4>},
-    {128, 256, 512, "lp_dual_simplex<16,32,8,8>", launch_cfg<16, 32, 8, 8>},
-    {192, 256, 512, "lp_dual_simplex<16,32,12,8>", launch_cfg<16, 32, 12, 8>},
+    // <waves, rows per thread, columns per thread>: rows <= waves * R, columns <= 64 * C
+    {32, 64, 64, "lp_dual_simplex<1,32,1>", launch_cfg<1, 32, 1>},
+    {64, 128, 256, "lp_dual_simplex<4,16,2>", launch_cfg<4, 16, 2>},
+    {128, 256, 512, "lp_dual_simplex<8,16,4>", launch_cfg<8, 16, 4>},
+    {192, 256, 512, "lp_dual_simplex<8,24,4>", launch_cfg<8, 24, 4>},
 };
 
 const KernelCfg *pick_cfg(int m, int n) {
@@ -97,26 +98,29 @@ int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t strea
 #ifdef MIPX_KPROF
         // profiling build: per-section cycle totals of wave 0, summed over the launch
         static unsigned long long *d_prof = nullptr;
-        if (!d_prof) HIP_TRY(ctx, hipMalloc((void **)&d_prof, 16 * 8));
-        HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, 16 * 8, stream));
+        if (!d_prof) HIP_TRY(ctx, hipMalloc((void **)&d_prof, 32 * 8));
+        HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, 32 * 8, stream));
         a.prof = d_prof;
+        a.prof_wave = getenv("MIPX_KPROF_WAVE") ? atoi(getenv("MIPX_KPROF_WAVE")) : 0;
         cfg->launch(a, batch, stream);
         HIP_TRY(ctx, hipStreamSynchronize(stream));
-        unsigned long long h[16];
+        unsigned long long h[32];
         HIP_TRY(ctx, hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost));
         if (getenv("MIPX_KPROF_PRINT")) {
-            const double it = h[12] ? (double)h[12] : 1.0, rf = h[13] ? (double)h[13] : 1.0;
-            const double lps = h[14] ? (double)h[14] : 1.0;
-            fprintf(stderr, "[kprof] %s batch %d  lps %llu iters %llu refactor pivots %llu\n"
-                    "  simplex cycles/iter: rowx %.0f ratio %.0f colx %.0f update+leave %.0f\n"
-                    "  refactor cycles/pivot: rowsel %.0f rowx %.0f update+colx %.0f\n"
-                    "  per LP: setup %.0f first colx %.0f value-init %.0f tail %.0f\n",
-                    cfg->name, batch, h[14], h[12], h[13], h[1] / it, h[3] / it, h[4] / it, h[0] / it,
-                    h[9] / rf, h[10] / rf, h[11] / rf, h[15] / lps, h[8] / lps, h[7] / lps, h[6] / lps);
+            const double it = h[16] ? (double)h[16] : 1.0, rf = h[17] ? (double)h[17] : 1.0;
+            const double lps = h[18] ? (double)h[18] : 1.0;
+            fprintf(stderr, "[kprof] %s batch %d wave %d  lps %llu iters %llu refactor pivots %llu\n"
+                    "  simplex cycles/iter: mailbox %.0f ratio+barrier %.0f publish %.0f | borders %.0f T %.0f barrier %.0f\n"
+                    "  refactor cycles/pivot: rowsel+barrier %.0f rowx+barrier %.0f | borders %.0f T %.0f nextcol %.0f\n"
+                    "  per LP: setup %.0f first col %.0f refactor-end %.0f value-init %.0f tail %.0f\n",
+                    cfg->name, batch, a.prof_wave, h[18], h[16], h[17], h[1] / it, h[3] / it, h[4] / it,
+                    h[2] / it, h[5] / it, h[0] / it, h[9] / rf, h[10] / rf, h[12] / rf, h[13] / rf,
+                    h[14] / rf, h[15] / lps, h[8] / lps, h[11] / lps, h[7] / lps, h[6] / lps);
         }
         return MIPX_OK;
 #else
         a.prof = nullptr;
+        a.prof_wave = 0;
         cfg->launch(a, batch, stream);
         HIP_TRY(ctx, hipGetLastError());
         return MIPX_OK;
