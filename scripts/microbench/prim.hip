@@ -92,6 +92,45 @@ __global__ __launch_bounds__(512) void prim(unsigned long long *out, int test, i
             }
             __syncthreads();
         }
+    } else if (test == 11) {  // 38 readlanes into SGPRs, consumed by 38 fma
+        for (int it = 0; it < N; it++) {
+            const int ql = (iacc + it) & 63;
+            double a[16];
+#pragma unroll
+            for (int ii = 0; ii < 16; ii++) {
+                const int lo = __builtin_amdgcn_readlane(__double2loint(T[ii]), ql);
+                const int hi = __builtin_amdgcn_readlane(__double2hiint(T[ii]), ql);
+                a[ii] = __hiloint2double(hi, lo);
+            }
+#pragma unroll
+            for (int ii = 0; ii < 16; ii++) T[ii] = fma(a[ii], 1e-9, T[ii]);
+        }
+    } else if (test == 12) {  // one lane writes 16 doubles (ds_write_b128 x8), waitcnt, atomic add by lane 0
+        for (int it = 0; it < N; it++) {
+            const int ql = (iacc + it) & 63;
+            if (lane == ql) {
+#pragma unroll
+                for (int ii = 0; ii < 16; ii++) buf[wave * 17 + ii] = T[ii];
+            }
+            if (lane == 0) __hip_atomic_fetch_add(&mail[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            iacc += it;
+        }
+    } else if (test == 13) {  // same, then drain (what a following s_waitcnt sees)
+        for (int it = 0; it < N; it++) {
+            const int ql = (iacc + it) & 63;
+            if (lane == ql) {
+#pragma unroll
+                for (int ii = 0; ii < 16; ii++) buf[wave * 17 + ii] = T[ii];
+            }
+            if (lane == 0) __hip_atomic_fetch_add(&mail[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            iacc += it;
+        }
+    } else if (test == 14) {  // full-wave ds_write_b64 + waitcnt (for comparison)
+        for (int it = 0; it < N; it++) {
+            buf[tid] = T[it & 15] + it;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
     } else if (test == 10) {  // s_memtime pair (cost of one profiling mark)
         for (int it = 0; it < N; it++) { iacc += (int)clock64(); }
     }
@@ -103,8 +142,8 @@ __global__ __launch_bounds__(512) void prim(unsigned long long *out, int test, i
 int main() {
     unsigned long long *d; hipMalloc(&d, 16 * 8);
     const char *names[] = {"empty loop", "barrier", "LDS hand-over (write,bar,read,bar)", "dependent LDS read", "16-way select chain + ds_write",
-                           "2x u32 DPP reduce + ballot pick", "16x readlane_f64 + writelane", "dependent f64 division", "64 fma", "atomic publish + poll + barrier", "clock64"};
-    for (int t = 0; t <= 10; t++) {
+                           "2x u32 DPP reduce + ballot pick", "16x readlane_f64 + writelane", "dependent f64 division", "64 fma", "atomic publish + poll + barrier", "clock64", "32 readlane + 16 fma", "1-lane 16 doubles write + atomic", "same + drain", "full-wave ds_write_b64 + drain"};
+    for (int t = 0; t <= 14; t++) {
         hipMemset(d, 0, 16 * 8);
         hipLaunchKernelGGL(prim, dim3(1), dim3(512), 0, 0, d, t, 1);
         hipDeviceSynchronize();

@@ -5,16 +5,18 @@
 // reference has no kernel.  Design:
 //
 //   * The condensed simplex tableau T (m x n, f64) lives in VGPRs for the whole solve: lane l of
-//     wave w owns T[w + NW*ii][l + 64*jj], ii < R, jj < C -- whole rows belong to one wave, a
-//     column to one lane position of every wave.  256x128 -> 8 waves x 64 lanes x 16x4 doubles =
-//     256 KiB of registers on one CU; it never touches HBM again after the initial coalesced read.
-//   * So the wave that holds the leaving row runs the ratio test straight from its registers, and
-//     every wave gets its part of the pivot column with v_readlane (into SGPRs, which feed the fma
-//     sweep as scalar operands): a pivot costs two workgroup barriers, not four.
-//   * The row border (beta0, basic values a + b*M, basic variable and its bounds) lives in the
-//     registers of the row wave, which picks the next leaving row while the other waves are
-//     still in the rank-1 update; it collects the pivot column through an LDS sequence counter
-//     instead of a barrier.  The column border (d, nonbasic variable/side) lives in LDS.
+//     tableau wave w owns T[w + NW*ii][l + 64*jj], ii < R, jj < C -- whole rows belong to one wave, a
+//     column to one lane position of every wave.  256x128 -> 7 waves x 64 lanes x 19x4 doubles of
+//     registers on one CU; it never touches HBM again after the initial coalesced read.
+//   * Wave 0 is the control wave: it holds no tableau rows but both borders in registers (reduced
+//     costs and nonbasic variable/side per column; beta0, basic values a + b*M, basic variable and
+//     its bounds per row) and runs every selection -- leaving row, Harris ratio test, the
+//     refactorisation's pivot rows.  The selections are chains of dependent instructions on one
+//     wave; the tableau waves' rank-1 update is throughput work.  Splitting them lets the next
+//     leaving row be chosen while the tableau waves are still in the fma sweep.
+//   * A tableau wave gets its part of the pivot column with v_readlane (into SGPRs, which feed the
+//     fma sweep as scalar operands) and hands a copy to the control wave through LDS and a
+//     sequence counter (no barrier); rows travel through LDS between two barriers.
 //   * Register arrays are only ever indexed statically: dynamic rows/columns are reached through
 //     wave-uniform (SGPR) select chains (no scratch).
 //   * Arithmetic is IEEE f64 with explicit fma and true division, compiled with
@@ -177,12 +179,20 @@ __device__ __forceinline__ int wave_pick(bool hit, int payload) {
         return __builtin_amdgcn_readlane(payload, __ffsll((long long)mask) - 1);
     return (int)wave_min_u32(hit ? (unsigned)payload : (unsigned)kNoCand);
 }
-// wave-wide argmax / argmin over keys >= +0 (lanes without a candidate carry payload kNoCand)
+// wave-wide argmax / argmin over keys >= +0 (lanes without a candidate carry payload kNoCand).
+// The low words are only reduced when the high word does not single out one lane.
 __device__ __forceinline__ int wave_argmax_pos(double key, int payload, double &kmax) {
     const bool valid = payload != kNoCand;
     const unsigned hi = valid ? (unsigned)__double2hiint(key) : 0u;
     const unsigned lo = valid ? (unsigned)__double2loint(key) : 0u;
     const unsigned hm = wave_max_u32(hi);
+    const unsigned long long m1 = __ballot(valid & (hi == hm));
+    if (m1 == 0ull) { kmax = 0.0; return kNoCand; }
+    if ((m1 & (m1 - 1ull)) == 0ull) {
+        const int l = __ffsll((long long)m1) - 1;
+        kmax = __hiloint2double((int)hm, __builtin_amdgcn_readlane((int)lo, l));
+        return __builtin_amdgcn_readlane(payload, l);
+    }
     const unsigned lm = wave_max_u32(hi == hm ? lo : 0u);
     kmax = __hiloint2double((int)hm, (int)lm);
     return wave_pick(valid & (hi == hm) & (lo == lm), payload);
@@ -192,6 +202,13 @@ __device__ __forceinline__ int wave_argmin_pos(double key, int payload, double &
     const unsigned hi = valid ? (unsigned)__double2hiint(key) : 0x7ff00000u;
     const unsigned lo = valid ? (unsigned)__double2loint(key) : 0u;
     const unsigned hm = wave_min_u32(hi);
+    const unsigned long long m1 = __ballot(valid & (hi == hm));
+    if (m1 == 0ull) { kmin = __builtin_huge_val(); return kNoCand; }
+    if ((m1 & (m1 - 1ull)) == 0ull) {
+        const int l = __ffsll((long long)m1) - 1;
+        kmin = __hiloint2double((int)hm, __builtin_amdgcn_readlane((int)lo, l));
+        return __builtin_amdgcn_readlane(payload, l);
+    }
     const unsigned lm = wave_min_u32(hi == hm ? lo : 0xffffffffu);
     kmin = __hiloint2double((int)hm, (int)lm);
     return wave_pick(valid & (hi == hm) & (lo == lm), payload);
@@ -263,48 +280,43 @@ __device__ __forceinline__ int rowsum_row(int lane, int rp) {
     return rp == 32 ? 2 * r16 + ((lane & 2) ? 1 : 0) : r16;
 }
 
-// mailboxes (one 16-byte LDS word each, so a reader needs a single ds_read_b128: the LDS pipe is
-// shared by all the waves of the workgroup and every DS instruction counts)
-struct alignas(16) MailA {  // row wave -> everybody
+// mailboxes (one 16-byte LDS word each, so a reader needs a single ds_read_b128)
+struct alignas(16) MailA {  // control wave -> tableau waves: the pivot row
     int win;     // refactor: leaving row or -1.  simplex: row | 0x8000 if sigma = -1 | cmd << 16
     int lvmeta;  // leaving variable << 3 | fixed << 2 | side it goes to
     double x;    // refactor: 1/p.  simplex: la (value a-part the leaving variable goes to)
 };
-struct alignas(16) MailB {  // ratio wave -> everybody
+struct alignas(16) MailB {  // control wave -> tableau waves: the pivot column
     int q;       // entering column or -1
     int ev;      // entering variable
     double pinv;
 };
-struct alignas(16) MailC {  // ratio wave -> row wave, wave 0
-    int nfake, degen;  // nonbasic columns at the symbolic bound M; consecutive degenerate steps
-    double dq;
-    double vaq, vbq;
-};
 
-template <int NW, int R, int C>
+template <int NW, int R, int C, int MP>
 struct Smem {
-    static constexpr int MP = NW * R, NP = 64 * C;
+    static constexpr int NP = 64 * C;
     double row[NP];     // pivot row T[r][.]
-    double alpha[NW * (R + 1)];  // pivot column, wave w's rows at [w*(R+1) ..): for the row wave
+    static constexpr int RS = (R + 2) & ~1;  // row stride of alpha: even, so parts stay 16-byte aligned
+    alignas(16) double alpha[NW * RS];  // pivot column, tableau wave w's rows at [w*RS ..)
     double lo[NP];      // structural bounds by variable index
     double up[NP];
     double va[NP];      // nonbasic values a + b*M by column
     double vb[NP];
-    double d[NP];       // reduced costs by column
-    double key[NP];     // x assembly
-    double beta0[MP];   // staging of the row border at setup / output (it lives in the row wave's
-    double ba[MP];      //   registers in between)
-    double bb[MP];
+    double d[NP];       // staging of the borders at setup / output (they live in the control wave's
+    double key[NP];     //   registers in between); key: x assembly
+    double beta0[MP];
+    double ba[NW * R];
+    double bb[NW * R];
     MailA mbA;
     MailB mbB;
-    MailC mbC;
     int bvar[MP];
     int meta[NP];       // nonbasic variable << 3 | fixed << 2 | side (0 lower, 1 upper, 2 fake upper)
     int nvar[NP];       // output staging
     int side[NP];
     int wlist[NP];      // columns of the variables the warm start wants basic, ascending variable
     int nw;
-    int seq;            // pivot columns published so far, one count per wave
+    int nfake0;
+    int seq;            // pivot column parts published so far (one count per tableau wave and column)
     int pos[NP + MP];   // column of each variable in the starting tableau, -1 if basic
     int8_t wantb[NP + MP];
     int8_t atup[NP + MP];
@@ -313,7 +325,7 @@ struct Smem {
 #endif
 };
 // position of row i in Smem::alpha
-#define MIPX_AIDX(i_) (((i_) % NW) * (R + 1) + (i_) / NW)
+#define MIPX_AIDX(i_) (((i_) % NW) * RS + (i_) / NW)
 // wave-uniform reads of the mailboxes: one ds_read_b128 each, fields moved to scalar registers
 __device__ __forceinline__ void read_mail(const MailA &mb, int &win, int &lvmeta, double &x) {
     const int4 v = *reinterpret_cast<const int4 *>(&mb);
@@ -327,17 +339,6 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
     ev = __builtin_amdgcn_readfirstlane(v.y);
     pinv = __hiloint2double(__builtin_amdgcn_readfirstlane(v.w), __builtin_amdgcn_readfirstlane(v.z));
 }
-__device__ __forceinline__ void read_mail_counts(const MailC &mb, int &nfake, int &degen, double &dq) {
-    const int4 v = *reinterpret_cast<const int4 *>(&mb);
-    nfake = __builtin_amdgcn_readfirstlane(v.x);
-    degen = __builtin_amdgcn_readfirstlane(v.y);
-    dq = __hiloint2double(__builtin_amdgcn_readfirstlane(v.w), __builtin_amdgcn_readfirstlane(v.z));
-}
-__device__ __forceinline__ void read_mail_values(const MailC &mb, double &vaq, double &vbq) {
-    const int4 v = *reinterpret_cast<const int4 *>(&mb.vaq);
-    vaq = __hiloint2double(__builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.x));
-    vbq = __hiloint2double(__builtin_amdgcn_readfirstlane(v.w), __builtin_amdgcn_readfirstlane(v.z));
-}
 
 // ---- building blocks of the kernel body.  Macros, not lambdas: the register tableau T must be
 // seen as plain local arrays with static indices from the first optimisation pass on, or it is
@@ -348,30 +349,31 @@ __device__ __forceinline__ void read_mail_values(const MailC &mb, double &vaq, d
         dst_ = arr_[0];                                                                     \
         _Pragma("unroll") for (int t_ = 1; t_ < n_; t_++) dst_ = (k_) == t_ ? arr_[t_] : dst_; \
     } while (0)
-// this wave's part of column q: out of lane q % 64 with v_readlane into al[] (scalar registers,
-// they feed the fma sweep), then across lanes 0..R-1 with v_writelane and to s.alpha with ONE
-// ds_write (for the row wave), then one count on s.seq
+// tableau wave: the lane that holds column q stores the wave's part of it in s.alpha, for the
+// control wave and for the wave itself: every lane reads it back (broadcast reads; a v_readlane
+// per value would cost ~10 cycles each); then one count on s.seq
 #define MIPX_PUBLISH_COL(q_)                                                                \
     do {                                                                                    \
-        const int qlane_ = (q_)&63, ql_ = (q_) >> 6;                                        \
-        _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == ql_) {                   \
-            _Pragma("unroll") for (int ii = 0; ii < R; ii++) al[ii] = readlane_f64(T[ii][jj], qlane_); \
+        const int ql_ = (q_) >> 6;                                                          \
+        if (lane == ((q_)&63)) {                                                            \
+            _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == ql_) {               \
+                _Pragma("unroll") for (int ii = 0; ii < R; ii++) s.alpha[tw * RS + ii] = T[ii][jj]; \
+            }                                                                               \
         }                                                                                   \
-        int plo_ = 0, phi_ = 0;                                                             \
-        _Pragma("unroll") for (int ii = 0; ii < R; ii++) {                                  \
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(plo_) : "s"(__double2loint(al[ii])), "n"(ii)); \
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(phi_) : "s"(__double2hiint(al[ii])), "n"(ii)); \
-        }                                                                                   \
-        if (lane < R) s.alpha[wave * (R + 1) + lane] = __hiloint2double(phi_, plo_);        \
+        /* same wave, LDS executes in order: only the compiler must not move the reads up */ \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                              \
+        __builtin_amdgcn_wave_barrier();                                                    \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                              \
+        _Pragma("unroll") for (int ii = 0; ii < R; ii++) al[ii] = s.alpha[tw * RS + ii];    \
         if (lane == 0) __hip_atomic_fetch_add(&s.seq, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
     } while (0)
-// the row wave waits until all NW parts of the current pivot column are in s.alpha
+// the control wave waits until all NW parts of the current pivot column are in s.alpha
 #define MIPX_AWAIT_COL(target_)                                                             \
     do {                                                                                    \
         while (__hip_atomic_load(&s.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (target_)) \
             __builtin_amdgcn_s_sleep(1);                                                    \
     } while (0)
-// T[r][.] -> s.row (by the wave that holds row r)
+// T[r][.] -> s.row (by the tableau wave that holds row r)
 #define MIPX_EXTRACT_ROW(r_)                                                                \
     do {                                                                                    \
         const int rl_ = (r_) / NW;                                                          \
@@ -397,26 +399,29 @@ __device__ __forceinline__ void read_mail_values(const MailC &mb, double &vaq, d
                 _Pragma("unroll") for (int ii = 0; ii < R; ii++) T[ii][jj] = -al[ii] * (pinv_); \
             }                                                                               \
         }                                                                                   \
-        if (wave == rw_) { /* row r <- row * (1/p), and 1/p at the pivot position */        \
+        if (tw == rw_) { /* row r <- row * (1/p), and 1/p at the pivot position */          \
             _Pragma("unroll") for (int ii = 0; ii < R; ii++) if (ii == rl_) {               \
                 _Pragma("unroll") for (int jj = 0; jj < C; jj++)                            \
                     T[ii][jj] = (lane == qlane_ && jj == ql_) ? (pinv_) : rh[jj];           \
             }                                                                               \
         }                                                                                   \
     } while (0)
-// wave 0's half of a pivot: d, and the variable that takes over column q (borders in LDS)
-#define MIPX_UPDATE_COLS(q_, pinv_, dq_, lvmeta_)                                           \
+// control wave: d after the pivot on (r, q), and the variable that takes over column q
+#define MIPX_UPDATE_COLS(q_, pinv_, lvmeta_)                                                \
     do {                                                                                    \
+        double dq_;                                                                         \
+        MIPX_PICK(dq_, cD, C, (q_) >> 6);                                                   \
+        dq_ = readlane_f64(dq_, (q_)&63);                                                   \
         _Pragma("unroll") for (int kk = 0; kk < C; kk++) {                                  \
             const int j = lane + 64 * kk;                                                   \
             const double rho_ = s.row[j] * (pinv_);                                         \
-            const double upd_ = fma(-(dq_), rho_, s.d[j]);                                  \
-            s.d[j] = j == (q_) ? -(dq_) * (pinv_) : upd_;                                   \
+            const double upd_ = fma(-dq_, rho_, cD[kk]);                                    \
+            cD[kk] = j == (q_) ? -dq_ * (pinv_) : upd_;                                     \
+            cM[kk] = j == (q_) ? (lvmeta_) : cM[kk];                                        \
         }                                                                                   \
-        if (lane == 0) s.meta[q_] = (lvmeta_);                                              \
     } while (0)
 
-// (a) the row wave's choice of the leaving row, or of the end of the solve, published for everybody:
+// (a) the control wave's choice of the leaving row, or of the end of the solve, published for everybody:
 // largest violation (violations of the symbolic bound M first), ties -> lowest variable index
 #define MIPX_LEAVE_SELECT()                                                                  \
     do {                                                                                     \
@@ -498,37 +503,41 @@ _Pragma("unroll")                                                               
             else if (!isinf(up)) { la_ = up; lb_ = 0.0; newside = 1; }                           \
             else { la_ = 0.0; lb_ = 1.0; newside = 2; }                                          \
             (void)lb_;                                                                           \
+            sel_win = win & 0xffff;                                                              \
+            sel_lvmeta = (lvv << 3) | newside | (lo == up ? 4 : 0);                              \
+            sel_la = la_;                                                                        \
             if (lane == 0) {                                                                     \
                 MailA mb_;                                                                       \
-                mb_.win = win & 0xffff;                                                                 \
-                mb_.lvmeta = (lvv << 3) | newside | (lo == up ? 4 : 0);                          \
+                mb_.win = sel_win;                                                               \
+                mb_.lvmeta = sel_lvmeta;                                                         \
                 mb_.x = la_;                                                                     \
                 s.mbA = mb_;                                                                     \
             }                                                                                    \
-        } else if (lane == 0) {                                                                  \
-            s.mbA.win = cmd << 16;                                                               \
+        } else {                                                                                 \
+            sel_win = cmd << 16;                                                                 \
+            if (lane == 0) s.mbA.win = cmd << 16;                                                \
         }                                                                                        \
     } while (0)
 
-// Roles.  Every wave holds whole rows of the tableau and takes part in the rank-1 update.  On top:
-//   * the row wave (wave 1; wave 0 on a single-wave tile) owns the row border in registers and
-//     picks the leaving row, as soon as it has the pivot column, while the others still update;
-//   * the wave that holds the leaving row runs the Harris ratio test on it;
-//   * wave 0 keeps the reduced costs (LDS) up to date.
-template <int NW, int R, int C>
-__global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
-    constexpr int NT = 64 * NW;
-    constexpr int MP = NW * R;
+// Roles: wave 0 is the control wave (borders in registers, every selection); waves 1..NW are the
+// tableau waves (whole rows of T in registers, rank-1 updates).  They meet at three barriers per
+// simplex iteration (row chosen / row published / column chosen) and two per refactorisation
+// pivot; the pivot column goes to the control wave through s.alpha and the s.seq counter.
+template <int NW, int R, int C, int MP>
+__global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
+    constexpr int NT = 64 * (NW + 1);
     constexpr int NP = 64 * C;
     static_assert((NP & (NP - 1)) == 0, "padded column count must be a power of two");
-    constexpr int PI = (MP + 63) / 64;   // rows per lane of the row wave
-    constexpr int RW = NW > 1 ? 1 : 0;   // the row wave
-    __shared__ Smem<NW, R, C> s;
+    static_assert(MP <= NW * R, "the tableau waves must cover every row");
+    constexpr int PI = (MP + 63) / 64;  // rows per lane of the control wave
+    constexpr int RS = (R + 2) & ~1;    // row stride of s.alpha
+    __shared__ Smem<NW, R, C, MP> s;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool isC = wave == 0, isR = wave == RW;
+    const bool ctl = wave == 0;
+    const int tw = wave - 1;  // tableau wave index
     const int m = g.m, n = g.n;
     const int nv = n + m;
     const double INF = __builtin_huge_val();
@@ -541,13 +550,14 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
     if (tid < 16) s.prof[tid] = 0;
     unsigned long long tprev = clock64();
 #endif
-    double T[R][C];  // T[ii][jj] = tableau[wave + NW*ii][lane + 64*jj]
-    double al[R];    // this wave's part of the current pivot column (wave-uniform: scalar registers)
-#pragma unroll
-    for (int ii = 0; ii < R; ii++) al[ii] = 0.0;
-    // row border, in the registers of the row wave: row i = lane + 64*kk
+    double T[R][C];  // tableau waves: T[ii][jj] = tableau[tw + NW*ii][lane + 64*jj]
+    double al[R];    // tableau waves: their part of the current pivot column
+    // control wave: column border (column j = lane + 64*kk) and row border (row i = lane + 64*kk)
+    double cD[C];    // reduced cost
+    int cM[C];       // nonbasic variable << 3 | fixed << 2 | side
     double rB0[PI], rBa[PI], rBb[PI], rLo[PI], rUp[PI];
     int rM[PI];      // basic variable << 2 | pivoted by the refactorisation << 1 | wanted basic
+    int aix[PI];     // position of row i in s.alpha
     const size_t src = g.slot ? (size_t)g.slot[node] : (size_t)node;
     const double *gA = g.A + (size_t)node * g.A_stride;
     const double *gb = g.b + (size_t)node * g.b_stride;
@@ -559,7 +569,13 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
     // ---- 0. T = -A, beta0 = -b, d = c, slack basis (or the anchor's tableau state) -----------
     const bool anchored = g.anchor_T != nullptr && vin != nullptr;
     const double sgn = anchored ? 1.0 : -1.0;
-    {
+#pragma unroll
+    for (int ii = 0; ii < R; ii++) {
+        al[ii] = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < C; jj++) T[ii][jj] = 0.0;
+    }
+    if (!ctl) {
         // every load is issued unconditionally from a clamped address (all requests in flight at
         // once, 512 contiguous bytes per wave instruction); the padding is zeroed afterwards
         const double *tsrc = anchored ? g.anchor_T : gA;
@@ -568,7 +584,7 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
         for (int jj = 0; jj < C; jj++) joff[jj] = min(lane + 64 * jj, n - 1);
 #pragma unroll
         for (int ii = 0; ii < R; ii++) {
-            const double *arow = tsrc + (size_t)min(wave + NW * ii, m > 0 ? m - 1 : 0) * n;
+            const double *arow = tsrc + (size_t)min(tw + NW * ii, m > 0 ? m - 1 : 0) * n;
 #pragma unroll
             for (int jj = 0; jj < C; jj++) T[ii][jj] = m > 0 ? arow[joff[jj]] : 0.0;
         }
@@ -576,7 +592,7 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
         for (int ii = 0; ii < R; ii++) {
 #pragma unroll
             for (int jj = 0; jj < C; jj++)
-                T[ii][jj] = (wave + NW * ii < m && lane + 64 * jj < n) ? sgn * T[ii][jj] : 0.0;
+                T[ii][jj] = (tw + NW * ii < m && lane + 64 * jj < n) ? sgn * T[ii][jj] : 0.0;
         }
     }
 #pragma unroll 1
@@ -620,48 +636,52 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
         }
         if (lane == 0) s.nw = cnt;
     }
-    // the row wave takes its border into registers
+    // the control wave takes the borders into registers
+#pragma unroll
+    for (int kk = 0; kk < C; kk++) {
+        cD[kk] = s.d[lane + 64 * kk];
+        cM[kk] = s.meta[lane + 64 * kk];
+    }
 #pragma unroll
     for (int kk = 0; kk < PI; kk++) {
         const int i = lane + 64 * kk;
-        const int v = i < MP ? s.bvar[i < MP ? i : 0] : -1;
+        const int ic = i < MP ? i : 0;
+        const int v = i < MP ? s.bvar[ic] : -1;
         const bool st = v >= 0 && v < n;
-        rB0[kk] = i < MP ? s.beta0[i < MP ? i : 0] : 0.0;
+        rB0[kk] = i < MP ? s.beta0[ic] : 0.0;
         rBa[kk] = 0.0;
         rBb[kk] = 0.0;
         rLo[kk] = st ? s.lo[st ? v : 0] : 0.0;
         rUp[kk] = st ? s.up[st ? v : 0] : INF;
         rM[kk] = (v << 2) | ((v >= 0 && s.wantb[v < 0 ? 0 : v]) ? 1 : 0);
+        aix[kk] = MIPX_AIDX(ic);
     }
     __syncthreads();
     const int nw = __builtin_amdgcn_readfirstlane(s.nw);
 
     int npiv = 0, iters = 0, status = -1;
     const int cap = 100 * (m + n) + 1000;
-    int cols = 0;  // pivot columns published so far (the row wave waits for NW * cols counts)
+    int cols = 0;  // pivot columns published so far (the control wave waits for NW * cols counts)
     KPROF_MARK(15);
 
     // ---- 1. refactor: pivot the wanted variables into the basis, ascending variable -----------
-    // Per pivot: every wave publishes its part of column q (after its own update of the previous
-    // pivot); the row wave picks the row; barrier; the wave holding row r publishes it; barrier;
-    // rank-1 update.  The row wave's choice overlaps the other waves' update.
+    // Per pivot: the tableau waves publish their parts of column q (after their update of the
+    // previous pivot); the control wave picks the row; barrier; the wave holding row r publishes
+    // it; barrier; rank-1 update / reduced costs.
     if (vin) {
-        if (nw > 0) {
-            MIPX_PUBLISH_COL(__builtin_amdgcn_readfirstlane(s.wlist[0]));
-            cols++;
-        }
-        KPROF_MARK(8);
-        for (int w = 0; w < nw;) {
-            const int q = __builtin_amdgcn_readfirstlane(s.wlist[w]);
-            if (isR) {  // leaving row: largest |T_iq| among rows whose basic variable is not wanted
+        if (ctl) {
+            for (int w = 0; w < nw; w++) {
+                const int q = __builtin_amdgcn_readfirstlane(s.wlist[w]);
+                cols++;
                 MIPX_AWAIT_COL(NW * cols);
+                // leaving row: largest |T_iq| among rows whose basic variable is not wanted
                 double k1 = -1.0, k2 = -1.0;  // (fallback: wanted, but not pivoted in yet)
                 int p1 = kNoCand, p2 = kNoCand;
                 double rc[PI], av[PI];
 #pragma unroll
                 for (int kk = 0; kk < PI; kk++) {
                     const int i = lane + 64 * kk;
-                    av[kk] = i < MP ? s.alpha[MIPX_AIDX(i < MP ? i : 0)] : 0.0;
+                    av[kk] = i < MP ? s.alpha[aix[kk]] : 0.0;
                     const double a = fabs(av[kk]);
                     const bool ok = i < m && a > kPivTol;
                     const bool wanted = rM[kk] & 1, ent = rM[kk] & 2;
@@ -672,24 +692,29 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
                 double km;
                 int rr = wave_argmax_pos(k1, p1, km);
                 if (rr == kNoCand) rr = wave_argmax_pos(k2, p2, km);
+                double pinv = 0.0;
+                int lvmeta = 0;
                 if (rr != kNoCand) {
                     double rcv, b0r;
                     int rmv;
                     MIPX_PICK(rcv, rc, PI, rr >> 6);
                     MIPX_PICK(rmv, rM, PI, rr >> 6);
                     MIPX_PICK(b0r, rB0, PI, rr >> 6);
-                    const double pinv = readlane_f64(rcv, rr & 63);
+                    pinv = readlane_f64(rcv, rr & 63);
                     const int lv = __builtin_amdgcn_readlane(rmv, rr & 63) >> 2;
                     const bool fix = lv < n && s.lo[lv < n ? lv : 0] == s.up[lv < n ? lv : 0];
+                    lvmeta = (lv << 3) | (fix ? 4 : 0);
                     if (lane == 0) {
                         MailA mb;
                         mb.win = rr;
-                        mb.lvmeta = (lv << 3) | (fix ? 4 : 0);
+                        mb.lvmeta = lvmeta;
                         mb.x = pinv;
                         s.mbA = mb;
                     }
                     // beta0 and the basis list, right away
-                    const int ev = __builtin_amdgcn_readfirstlane(s.meta[q]) >> 3;
+                    int cmq;
+                    MIPX_PICK(cmq, cM, C, q >> 6);
+                    const int ev = __builtin_amdgcn_readlane(cmq, q & 63) >> 3;
                     const double rhon = readlane_f64(b0r, rr & 63) * pinv;
                     const double elo = ev < n ? s.lo[ev < n ? ev : 0] : 0.0;
                     const double eup = ev < n ? s.up[ev < n ? ev : 0] : INF;
@@ -703,71 +728,65 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
                         rLo[kk] = pr ? elo : rLo[kk];
                         rUp[kk] = pr ? eup : rUp[kk];
                     }
+                    npiv++;
                 } else if (lane == 0) {
                     s.mbA.win = -1;  // singular: the variable stays nonbasic
                 }
-            }
-            __syncthreads();
-            KPROF_MARK(9);
-            int r, lvmeta;
-            double pinv;
-            read_mail(s.mbA, r, lvmeta, pinv);
-            if (r >= 0 && wave == r % NW) MIPX_EXTRACT_ROW(r);
-            __syncthreads();
-            KPROF_MARK(10);
-            if (r >= 0) {
-                if (isC) {
-                    const double dq = uniform_f64(s.d[q]);
-                    MIPX_UPDATE_COLS(q, pinv, dq, lvmeta);
-                }
+                KPROF_MARK(9);
+                __syncthreads();  // A: row chosen
+                __syncthreads();  // B: row published
+                KPROF_MARK(10);
+                if (rr != kNoCand) MIPX_UPDATE_COLS(q, pinv, lvmeta);
                 KPROF_MARK(12);
-                MIPX_UPDATE_T(r, q, pinv);
+            }
+        } else {
+            if (nw > 0) MIPX_PUBLISH_COL(__builtin_amdgcn_readfirstlane(s.wlist[0]));
+            for (int w = 0; w < nw; w++) {
+                const int q = __builtin_amdgcn_readfirstlane(s.wlist[w]);
+                __syncthreads();  // A
+                int r, lvmeta;
+                double pinv;
+                read_mail(s.mbA, r, lvmeta, pinv);
+                if (r >= 0 && tw == r % NW) MIPX_EXTRACT_ROW(r);
+                __syncthreads();  // B
+                KPROF_MARK(10);
+                if (r >= 0) MIPX_UPDATE_T(r, q, pinv);
                 KPROF_MARK(13);
-                npiv++;
+                if (w + 1 < nw)  // next column, from registers already updated
+                    MIPX_PUBLISH_COL(__builtin_amdgcn_readfirstlane(s.wlist[w + 1 < nw ? w + 1 : 0]));
+                KPROF_MARK(14);
             }
-            w++;
-            if (w < nw) {  // next column, from registers already updated
-                MIPX_PUBLISH_COL(__builtin_amdgcn_readfirstlane(s.wlist[w < nw ? w : 0]));
-                cols++;
-            }
-            KPROF_MARK(14);
         }
-        __syncthreads();
-        KPROF_MARK(11);
     }
 
     if (!(vin && g.refactor_only)) {
-        // ---- 2. nonbasic sides and values (wave 0), then the basic values ---------------------
-        if (isC) {
-            int fakes = 0;
+        // ---- 2. nonbasic sides and values (control wave), then the basic values ---------------
+        int nfake = 0;  // nonbasic columns at the symbolic bound M (control wave)
+        if (ctl) {
 #pragma unroll
             for (int kk = 0; kk < C; kk++) {
                 const int j = lane + 64 * kk;
                 int side = 0;
                 if (j < n) {
-                    const int mt = s.meta[j];
-                    const int v = mt >> 3;
+                    const int v = cM[kk] >> 3;
                     const double lo = v < n ? s.lo[v < n ? v : 0] : 0.0;
                     const double up = v < n ? s.up[v < n ? v : 0] : INF;
-                    const double dj = s.d[j];
+                    const double dj = cD[kk];
                     if (lo == up) side = 0;
                     else if (dj < -kDTol) side = isinf(up) ? 2 : 1;
                     else if (dj > kDTol) side = 0;
                     else side = (s.atup[v] && !isinf(up)) ? 1 : 0;
                     s.va[j] = side == 0 ? lo : side == 1 ? up : 0.0;
                     s.vb[j] = side == 2 ? 1.0 : 0.0;
-                    s.meta[j] = (mt & ~3) | side;
                 }
-                fakes += __popcll(__ballot(side == 2));
+                cM[kk] = (cM[kk] & ~3) | side;
+                nfake += __popcll(__ballot(side == 2));
             }
-            if (lane == 0) {
-                s.mbC.nfake = fakes;
-                s.mbC.degen = 0;
-            }
+            if (lane == 0) s.nfake0 = nfake;
         }
         __syncthreads();
-        int nfk = __builtin_amdgcn_readfirstlane(s.mbC.nfake);
-        {
+        if (!ctl) {
+            const int nf0 = __builtin_amdgcn_readfirstlane(s.nfake0);
             constexpr int RP = R <= 16 ? 16 : 32;
             double va[C], vb[C];
 #pragma unroll
@@ -775,7 +794,7 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
                 va[jj] = s.va[lane + 64 * jj];
                 vb[jj] = s.vb[lane + 64 * jj];
             }
-            double pa[RP], pb[RP];
+            double pr[RP];
 #pragma unroll
             for (int ii = 0; ii < RP; ii++) {
                 double t[C];
@@ -786,11 +805,12 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
 #pragma unroll
                     for (int jj = 0; jj < h; jj++) t[jj] = t[jj] + t[jj + h];
                 }
-                pa[ii] = t[0];
-                pb[ii] = 0.0;
+                pr[ii] = t[0];
             }
-            MIPX_ROWSUMS(pa, RP);
-            if (nfk != 0) {  // the M parts: all zero unless some nonbasic sits at the symbolic bound
+            MIPX_ROWSUMS(pr, RP);
+            const double sa = pr[0];
+            double sb = 0.0;
+            if (nf0 != 0) {  // the M parts: all zero unless some nonbasic sits at the symbolic bound
 #pragma unroll
                 for (int ii = 0; ii < RP; ii++) {
                     double t[C];
@@ -801,26 +821,33 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
 #pragma unroll
                         for (int jj = 0; jj < h; jj++) t[jj] = t[jj] + t[jj + h];
                     }
-                    pb[ii] = t[0];
+                    pr[ii] = t[0];
                 }
-                MIPX_ROWSUMS(pb, RP);
+                MIPX_ROWSUMS(pr, RP);
+                sb = pr[0];
             }
             const int ii = rowsum_row(lane, RP);
             if ((lane & (RP == 32 ? 1 : 3)) == 0 && ii < R) {
-                s.ba[wave + NW * ii] = pa[0];
-                s.bb[wave + NW * ii] = 0.0 - pb[0];
+                s.ba[tw + NW * ii] = sa;
+                s.bb[tw + NW * ii] = 0.0 - sb;
             }
         }
         __syncthreads();
         KPROF_MARK(7);
 
         // ---- 3. dual simplex ------------------------------------------------------------------
-        // The row wave picks the leaving row r; barrier; the wave holding row r publishes it and
-        // runs the ratio test; barrier; every wave publishes its part of column q and updates its
-        // rows, the row wave going through the border update and the next choice first.
-        bool bland = false;
-        double sel_b0 = 0.0, sel_ba = 0.0, sel_bb = 0.0;  // border values of row r (row wave)
-        if (isR) {
+        // Control wave: leaving row r | A | (row r arrives) | B | ratio test: column q | C | reduced
+        // costs, wait for column q, basic values, next leaving row | A ...
+        // Tableau waves: | A | the wave holding row r publishes it | B | | C | column parts out,
+        // rank-1 update | A ...
+        if (ctl) {
+            bool bland = false;
+            int degen = 0;  // consecutive degenerate steps; > m+n -> Bland's rule
+            const int nfk0 = nfake;
+            int nfk = nfk0;
+            double sel_b0 = 0.0, sel_ba = 0.0, sel_bb = 0.0;  // border values of row r
+            int sel_win = 0, sel_lvmeta = 0;
+            double sel_la = 0.0;
 #pragma unroll
             for (int kk = 0; kk < PI; kk++) {
                 const int i = lane + 64 * kk;
@@ -828,62 +855,38 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
                 rBb[kk] = i < MP ? s.bb[i < MP ? i : 0] : 0.0;
             }
             MIPX_LEAVE_SELECT();
-        }
-        __syncthreads();
-        for (;;) {
-            int win, lvmeta;
-            double la;
-            read_mail(s.mbA, win, lvmeta, la);
-            const int cmd = win >> 16;
-            if (cmd) { status = cmd == 1 ? 0 : cmd == 3 ? 2 : 3; break; }
-            const int r = win & 0x7fff;
-            const double lb = (lvmeta & 3) == 2 ? 1.0 : 0.0;
-            KPROF_MARK(1);
-            if (wave == r % NW) {  // (b, c) row r, and the Harris ratio test on it
-                const unsigned sflip = (win & 0x8000) ? 0x80000000u : 0u;  // sigma = -1
-                int nfake, degen;
-                double dq_unused;
-                read_mail_counts(s.mbC, nfake, degen, dq_unused);
-                const bool bl = degen > m + n;
-                double rv[C];
-                const int rl = r / NW;
-#pragma unroll
-                for (int jj = 0; jj < C; jj++) rv[jj] = 0.0;
-#pragma unroll
-                for (int ii = 0; ii < R; ii++)
-                    if (ii == rl) {
-#pragma unroll
-                        for (int jj = 0; jj < C; jj++) rv[jj] = T[ii][jj];
-                    }
-#pragma unroll
-                for (int jj = 0; jj < C; jj++) s.row[lane + 64 * jj] = rv[jj];
-                double aa[C], dje[C], rc[C], dd[C];
-                int mt[C];
+            __syncthreads();  // A
+            for (;;) {
+                if (sel_win >> 16) { const int cmd = sel_win >> 16; status = cmd == 1 ? 0 : cmd == 3 ? 2 : 3; break; }
+                const int r = sel_win & 0x7fff;
+                const int lvmeta = sel_lvmeta;
+                const double la = sel_la, lb = (lvmeta & 3) == 2 ? 1.0 : 0.0;
+                const unsigned sflip = (sel_win & 0x8000) ? 0x80000000u : 0u;  // sigma = -1
+                KPROF_MARK(1);
+                __syncthreads();  // B: row r is in s.row
+                // (c) Harris ratio test on row r
+                double aa[C], dje[C], rc[C];
                 bool el[C];
                 double k1 = INF;
                 int p1 = kNoCand;
-                const double tol = bl ? 0.0 : kDTol;  // Bland: the textbook ratio dj / |a|
-#pragma unroll
-                for (int kk = 0; kk < C; kk++) {
-                    dd[kk] = s.d[lane + 64 * kk];
-                    mt[kk] = s.meta[lane + 64 * kk];
-                }
+                const double tol = bland ? 0.0 : kDTol;  // Bland: the textbook ratio dj / |a|
 #pragma unroll
                 for (int kk = 0; kk < C; kk++) {
                     const int j = lane + 64 * kk;
-                    const double a = __hiloint2double(__double2hiint(rv[kk]) ^ sflip, __double2loint(rv[kk]));
-                    const int sd = mt[kk] & 3;
-                    el[kk] = ((mt[kk] & 4) == 0) & (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
-                    dje[kk] = sd == 0 ? fmax(dd[kk], 0.0) : fmax(-dd[kk], 0.0);
+                    const double rv = s.row[j];
+                    const double a = __hiloint2double(__double2hiint(rv) ^ sflip, __double2loint(rv));
+                    const int sd = cM[kk] & 3;
+                    el[kk] = ((cM[kk] & 4) == 0) & (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
+                    dje[kk] = sd == 0 ? fmax(cD[kk], 0.0) : fmax(-cD[kk], 0.0);
                     aa[kk] = fabs(a);
                     const double key = (dje[kk] + tol) / aa[kk];  // unconditionally: no divergent branch
-                    rc[kk] = 1.0 / rv[kk];                        // 1/p of every candidate, likewise
-                    keep_min(k1, p1, key, ((mt[kk] >> 3) << 16) | j, el[kk]);
+                    rc[kk] = 1.0 / rv;                            // 1/p of every candidate, likewise
+                    keep_min(k1, p1, key, ((cM[kk] >> 3) << 16) | j, el[kk]);
                 }
                 double thmax;
                 const int w1 = wave_argmin_pos(k1, p1, thmax);
                 int qq = -1;
-                if (w1 != kNoCand && bl) {
+                if (w1 != kNoCand && bland) {
                     qq = w1 & 0xffff;  // ties -> lowest variable index
                 } else if (w1 != kNoCand) {
                     const int jmin = w1 & 0xffff;
@@ -893,92 +896,101 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
                     for (int kk = 0; kk < C; kk++) {
                         const int j = lane + 64 * kk;
                         const bool ok = el[kk] & ((j == jmin) | !(dje[kk] > thmax * aa[kk]));
-                        keep_max(k2, p2, aa[kk], ((mt[kk] >> 3) << 16) | j, ok);
+                        keep_max(k2, p2, aa[kk], ((cM[kk] >> 3) << 16) | j, ok);
                     }
                     double amax;
                     qq = wave_argmax_pos(k2, p2, amax) & 0xffff;
                 }
+                double pinv = 0.0, vaq = 0.0, vbq = 0.0;
+                int ev = 0;
                 if (qq >= 0) {
                     const int ql = qq & 63, qk = qq >> 6;
-                    double t0, t1, t2;
+                    double t0, t1;
                     int tm;
                     MIPX_PICK(t0, dje, C, qk);
                     MIPX_PICK(t1, rc, C, qk);
-                    MIPX_PICK(t2, dd, C, qk);
-                    MIPX_PICK(tm, mt, C, qk);
+                    MIPX_PICK(tm, cM, C, qk);
                     const double djq = readlane_f64(t0, ql);
                     const int cm = __builtin_amdgcn_readlane(tm, ql);
                     degen = djq <= kDTol ? degen + 1 : 0;
-                    nfake += ((lvmeta & 3) == 2 ? 1 : 0) - ((cm & 3) == 2 ? 1 : 0);
-                    const double pv = readlane_f64(t1, ql), dq = readlane_f64(t2, ql);
-                    const double vaq = s.va[qq], vbq = s.vb[qq];
+                    bland = degen > m + n;
+                    nfk += ((lvmeta & 3) == 2 ? 1 : 0) - ((cm & 3) == 2 ? 1 : 0);
+                    pinv = readlane_f64(t1, ql);
+                    ev = cm >> 3;
                     if (lane == 0) {
                         MailB mb;
                         mb.q = qq;
-                        mb.ev = cm >> 3;
-                        mb.pinv = pv;
+                        mb.ev = ev;
+                        mb.pinv = pinv;
                         s.mbB = mb;
-                        MailC mc;
-                        mc.nfake = nfake;
-                        mc.degen = degen;
-                        mc.dq = dq;
-                        mc.vaq = vaq;
-                        mc.vbq = vbq;
-                        s.mbC = mc;
                     }
+                    vaq = uniform_f64(s.va[qq]);
+                    vbq = uniform_f64(s.vb[qq]);
                 } else if (lane == 0) {
                     s.mbB.q = -1;
                 }
-            }
-            __syncthreads();
-            KPROF_MARK(3);
-            int q, ev;
-            double pinv;
-            read_mail(s.mbB, q, ev, pinv);
-            if (q < 0) { status = 1; break; }  // no entering column: primal infeasible
-            MIPX_PUBLISH_COL(q);  // (d)
-            cols++;
-            iters++;
-            npiv++;
-            KPROF_MARK(4);
-            if (isR) {  // basic values after the pivot on (r, q), then the next leaving row
-                int dg;
-                double dq_unused, vaq, vbq;
-                read_mail_counts(s.mbC, nfk, dg, dq_unused);
-                read_mail_values(s.mbC, vaq, vbq);
-                bland = dg > m + n;
-                const double rhon = sel_b0 * pinv;
-                const double ta = (sel_ba - la) * pinv, tb = (sel_bb - lb) * pinv;
-                const double elo = ev < n ? s.lo[ev < n ? ev : 0] : 0.0;
-                const double eup = ev < n ? s.up[ev < n ? ev : 0] : INF;
-                MIPX_AWAIT_COL(NW * cols);
-#pragma unroll
-                for (int kk = 0; kk < PI; kk++) {
-                    const int i = lane + 64 * kk;
-                    const double a = i < MP ? s.alpha[MIPX_AIDX(i < MP ? i : 0)] : 0.0;
-                    const bool pr = i == r;
-                    const double u0 = fma(-a, rhon, rB0[kk]), u1 = fma(-a, ta, rBa[kk]), u2 = fma(-a, tb, rBb[kk]);
-                    rB0[kk] = pr ? rhon : u0;
-                    rBa[kk] = pr ? vaq + ta : u1;
-                    rBb[kk] = pr ? vbq + tb : u2;
-                    rM[kk] = pr ? (ev << 2) : rM[kk];
-                    rLo[kk] = pr ? elo : rLo[kk];
-                    rUp[kk] = pr ? eup : rUp[kk];
-                }
-                MIPX_LEAVE_SELECT();
-            }
-            if (isC) {
-                int nf_, dg_;
-                double dq;
-                read_mail_counts(s.mbC, nf_, dg_, dq);
-                MIPX_UPDATE_COLS(q, pinv, dq, lvmeta);
+                KPROF_MARK(3);
+                __syncthreads();  // C: column chosen
+                if (qq < 0) { status = 1; break; }  // no entering column: primal infeasible
+                const int q = qq;
+                iters++;
+                npiv++;
+                cols++;
+                MIPX_UPDATE_COLS(q, pinv, lvmeta);
                 if (lane == 0) { s.va[q] = la; s.vb[q] = lb; }
+                KPROF_MARK(2);
+                {   // basic values after the pivot on (r, q), then the next leaving row
+                    const double rhon = sel_b0 * pinv;
+                    const double ta = (sel_ba - la) * pinv, tb = (sel_bb - lb) * pinv;
+                    const double elo = ev < n ? s.lo[ev < n ? ev : 0] : 0.0;
+                    const double eup = ev < n ? s.up[ev < n ? ev : 0] : INF;
+                    MIPX_AWAIT_COL(NW * cols);
+                    KPROF_MARK(4);
+#pragma unroll
+                    for (int kk = 0; kk < PI; kk++) {
+                        const int i = lane + 64 * kk;
+                        const double a = i < MP ? s.alpha[aix[kk]] : 0.0;
+                        const bool pr = i == r;
+                        const double u0 = fma(-a, rhon, rB0[kk]), u1 = fma(-a, ta, rBa[kk]), u2 = fma(-a, tb, rBb[kk]);
+                        rB0[kk] = pr ? rhon : u0;
+                        rBa[kk] = pr ? vaq + ta : u1;
+                        rBb[kk] = pr ? vbq + tb : u2;
+                        rM[kk] = pr ? (ev << 2) : rM[kk];
+                        rLo[kk] = pr ? elo : rLo[kk];
+                        rUp[kk] = pr ? eup : rUp[kk];
+                    }
+                    MIPX_LEAVE_SELECT();
+                }
+                KPROF_MARK(5);
+                __syncthreads();  // A: row chosen
+                KPROF_MARK(0);
             }
-            KPROF_MARK(2);
-            MIPX_UPDATE_T(r, q, pinv);
-            KPROF_MARK(5);
-            __syncthreads();
-            KPROF_MARK(0);
+            (void)nfk0;
+        } else {
+            __syncthreads();  // A
+            for (;;) {
+                int win, lvmeta;
+                double la;
+                read_mail(s.mbA, win, lvmeta, la);
+                if (win >> 16) break;
+                const int r = win & 0x7fff;
+                if (tw == r % NW) MIPX_EXTRACT_ROW(r);  // (b)
+                KPROF_MARK(1);
+                __syncthreads();  // B
+                __syncthreads();  // C
+                KPROF_MARK(3);
+                int q, ev;
+                double pinv;
+                read_mail(s.mbB, q, ev, pinv);
+                if (q < 0) break;
+                KPROF_MARK(8);
+                MIPX_PUBLISH_COL(q);  // (d)
+                KPROF_MARK(4);
+                MIPX_UPDATE_T(r, q, pinv);
+                KPROF_MARK(5);
+                __syncthreads();  // A
+                KPROF_MARK(0);
+            }
         }
     } else {
         status = 3;
@@ -995,11 +1007,14 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
         atomicAdd(&g.prof[18], 1ull);
     }
 #endif
-    for (int j = tid; j < NP; j += NT) {
-        s.nvar[j] = s.meta[j] >> 3;
-        s.side[j] = s.meta[j] & 3;
-    }
-    if (isR) {
+    if (ctl) {
+#pragma unroll
+        for (int kk = 0; kk < C; kk++) {
+            const int j = lane + 64 * kk;
+            s.d[j] = cD[kk];
+            s.nvar[j] = cM[kk] >> 3;
+            s.side[j] = cM[kk] & 3;
+        }
 #pragma unroll
         for (int kk = 0; kk < PI; kk++) {
             const int i = lane + 64 * kk;
@@ -1045,8 +1060,8 @@ __global__ __launch_bounds__(64 * NW) void lp_dual_simplex(LpArgs g) {
         for (int ii = 0; ii < R; ii++) {
 #pragma unroll
             for (int jj = 0; jj < C; jj++) {
-                const int i = wave + NW * ii, j = lane + 64 * jj;
-                if (i < m && j < n) dT[(size_t)i * n + j] = T[ii][jj];
+                const int i = tw + NW * ii, j = lane + 64 * jj;
+                if (!ctl && i < m && j < n) dT[(size_t)i * n + j] = T[ii][jj];
             }
         }
         for (int j = tid; j < n; j += NT) {

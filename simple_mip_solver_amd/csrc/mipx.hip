@@ -65,18 +65,19 @@ struct KernelCfg {
     void (*launch)(const mipx::LpArgs &, int grid, hipStream_t);
 };
 
-template <int NW, int R, int C>
+template <int NW, int R, int C, int MP>
 void launch_cfg(const mipx::LpArgs &a, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((mipx::lp_dual_simplex<NW, R, C>), dim3(grid), dim3(64 * NW), 0, st, a);
+    hipLaunchKernelGGL((mipx::lp_dual_simplex<NW, R, C, MP>), dim3(grid), dim3(64 * (NW + 1)), 0, st, a);
 }
 
 // ordered by on-chip footprint; the first that fits (m <= mp, n <= np) is used
 const KernelCfg kCfgs[] = {
-    // <waves, rows per thread, columns per thread>: rows <= waves * R, columns <= 64 * C
-    {32, 64, 64, "lp_dual_simplex<1,32,1>", launch_cfg<1, 32, 1>},
-    {64, 128, 256, "lp_dual_simplex<4,16,2>", launch_cfg<4, 16, 2>},
-    {128, 256, 512, "lp_dual_simplex<8,16,4>", launch_cfg<8, 16, 4>},
-    {192, 256, 512, "lp_dual_simplex<8,24,4>", launch_cfg<8, 24, 4>},
+    // <tableau waves, rows per thread, columns per thread> (+ one control wave):
+    // rows <= waves * R, columns <= 64 * C
+    {32, 64, 128, "lp_dual_simplex<1,32,1>", launch_cfg<1, 32, 1, 32>},
+    {64, 128, 256, "lp_dual_simplex<3,22,2>", launch_cfg<3, 22, 2, 64>},
+    {128, 256, 512, "lp_dual_simplex<7,19,4>", launch_cfg<7, 19, 4, 128>},
+    {192, 256, 512, "lp_dual_simplex<7,28,4>", launch_cfg<7, 28, 4, 192>},
 };
 
 const KernelCfg *pick_cfg(int m, int n) {
@@ -110,12 +111,14 @@ int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t strea
             const double it = h[16] ? (double)h[16] : 1.0, rf = h[17] ? (double)h[17] : 1.0;
             const double lps = h[18] ? (double)h[18] : 1.0;
             fprintf(stderr, "[kprof] %s batch %d wave %d  lps %llu iters %llu refactor pivots %llu\n"
-                    "  simplex cycles/iter: mailbox %.0f ratio+barrier %.0f publish %.0f | borders %.0f T %.0f barrier %.0f\n"
-                    "  refactor cycles/pivot: rowsel+barrier %.0f rowx+barrier %.0f | borders %.0f T %.0f nextcol %.0f\n"
-                    "  per LP: setup %.0f first col %.0f refactor-end %.0f value-init %.0f tail %.0f\n",
-                    cfg->name, batch, a.prof_wave, h[18], h[16], h[17], h[1] / it, h[3] / it, h[4] / it,
-                    h[2] / it, h[5] / it, h[0] / it, h[9] / rf, h[10] / rf, h[12] / rf, h[13] / rf,
-                    h[14] / rf, h[15] / lps, h[8] / lps, h[11] / lps, h[7] / lps, h[6] / lps);
+                    "  simplex cycles/iter: m1 %.0f m3 %.0f m2 %.0f m4 %.0f m5 %.0f m0 %.0f  (sum %.0f)\n"
+                    "  refactor cycles/pivot: m9 %.0f m10 %.0f m12 %.0f m13 %.0f m14 %.0f  (sum %.0f)\n"
+                    "  per LP: setup %.0f m8/iter %.0f m11 %.0f value-init %.0f tail %.0f\n",
+                    cfg->name, batch, a.prof_wave, h[18], h[16], h[17], h[1] / it, h[3] / it, h[2] / it,
+                    h[4] / it, h[5] / it, h[0] / it, (h[0] + h[1] + h[2] + h[3] + h[4] + h[5]) / it,
+                    h[9] / rf, h[10] / rf, h[12] / rf, h[13] / rf, h[14] / rf,
+                    (h[9] + h[10] + h[12] + h[13] + h[14]) / rf, h[15] / lps, h[8] / it, h[11] / lps,
+                    h[7] / lps, h[6] / lps);
         }
         return MIPX_OK;
 #else

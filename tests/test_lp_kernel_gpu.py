@@ -114,9 +114,9 @@ def test_s3_root_children_and_probes(gpu_ctx, oracle):
 
 
 def test_with_extra_rows_uses_tall_kernel(gpu_ctx, oracle):
-    # m > 128 (cut rows appended) dispatches to the R=24 instantiation
+    # m > 128 (cut rows appended) dispatches to the R=28 instantiation
     A, b, c, l, u, _ = random_dense_milp_arrays(200, 150, seed=3)
-    assert '24' in _ffi.kernel_name(150, 200)
+    assert '28' in _ffi.kernel_name(150, 200)
     p = _ffi.Problem(gpu_ctx, A, b, c)
     g = p.solve_batch(l[None], u[None])
     o = oracle.lp_solve_batch(A, b, c, l[None], u[None])
