@@ -131,6 +131,33 @@ __global__ __launch_bounds__(512) void prim(unsigned long long *out, int test, i
             buf[tid] = T[it & 15] + it;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+    } else if (test == 15) {  // 16 doubles broadcast read (uniform address), consumed
+        for (int it = 0; it < N; it++) {
+            const double *src = &buf[(wave * 17 + (it & 1)) & 1023];
+            double a[16];
+#pragma unroll
+            for (int ii = 0; ii < 16; ii++) a[ii] = src[ii];
+#pragma unroll
+            for (int ii = 0; ii < 16; ii++) T[ii] = fma(a[ii], 1e-9, T[ii]);
+        }
+    } else if (test == 16) {  // 1-lane write of 16 doubles, then broadcast read-back by the wave, consumed
+        for (int it = 0; it < N; it++) {
+            const int ql = (iacc + it) & 63;
+            double *dst = &buf[wave * 18];
+            if (lane == ql) {
+#pragma unroll
+                for (int ii = 0; ii < 16; ii++) dst[ii] = T[ii];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double a[16];
+#pragma unroll
+            for (int ii = 0; ii < 16; ii++) a[ii] = dst[ii];
+#pragma unroll
+            for (int ii = 0; ii < 16; ii++) T[ii] = fma(a[ii], 1e-9, T[ii]);
+            iacc += it;
+        }
     } else if (test == 10) {  // s_memtime pair (cost of one profiling mark)
         for (int it = 0; it < N; it++) { iacc += (int)clock64(); }
     }
@@ -142,8 +169,8 @@ __global__ __launch_bounds__(512) void prim(unsigned long long *out, int test, i
 int main() {
     unsigned long long *d; hipMalloc(&d, 16 * 8);
     const char *names[] = {"empty loop", "barrier", "LDS hand-over (write,bar,read,bar)", "dependent LDS read", "16-way select chain + ds_write",
-                           "2x u32 DPP reduce + ballot pick", "16x readlane_f64 + writelane", "dependent f64 division", "64 fma", "atomic publish + poll + barrier", "clock64", "32 readlane + 16 fma", "1-lane 16 doubles write + atomic", "same + drain", "full-wave ds_write_b64 + drain"};
-    for (int t = 0; t <= 14; t++) {
+                           "2x u32 DPP reduce + ballot pick", "16x readlane_f64 + writelane", "dependent f64 division", "64 fma", "atomic publish + poll + barrier", "clock64", "32 readlane + 16 fma", "1-lane 16 doubles write + atomic", "same + drain", "full-wave ds_write_b64 + drain", "16 doubles broadcast read + 16 fma", "1-lane write 16 + read-back + 16 fma"};
+    for (int t = 0; t <= 16; t++) {
         hipMemset(d, 0, 16 * 8);
         hipLaunchKernelGGL(prim, dim3(1), dim3(512), 0, 0, d, t, 1);
         hipDeviceSynchronize();

@@ -75,6 +75,11 @@ struct LpArgs {
 #else
 #define KPROF_MARK(k) do { } while (0)
 #endif
+#ifdef MIPX_KPROF_SETUP
+#define KPROF_SETUP_MARK(k) KPROF_MARK(k)
+#else
+#define KPROF_SETUP_MARK(k) do { } while (0)
+#endif
 
 // ---- wavefront-wide reductions on DPP (row_shr prefix-doubling inside each row of 16 lanes,
 // then row_bcast:15 / row_bcast:31 across rows; the total lands in lane 63 and is read back with
@@ -212,6 +217,34 @@ __device__ __forceinline__ int wave_argmin_pos(double key, int payload, double &
     const unsigned lm = wave_min_u32(hi == hm ? lo : 0xffffffffu);
     kmin = __hiloint2double((int)hm, (int)lm);
     return wave_pick(valid & (hi == hm) & (lo == lm), payload);
+}
+// N independent f64 divisions num/den, written step by step across the N so that the N dependent
+// chains (12 instructions each) overlap; the sequence is the standard correctly-rounded one
+// (v_div_scale / v_rcp / fma refinement / v_div_fmas / v_div_fixup), i.e. bit-identical to '/'.
+template <int N>
+__device__ __forceinline__ void div_n(const double (&num)[N], const double (&den)[N], double (&q)[N]) {
+    double d0[N], r[N], f[N], n1[N], mul[N];
+    bool fl[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) { bool t; d0[k] = __builtin_amdgcn_div_scale(num[k], den[k], false, &t); }
+#pragma unroll
+    for (int k = 0; k < N; k++) r[k] = __builtin_amdgcn_rcp(d0[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) f[k] = __builtin_fma(-d0[k], r[k], 1.0);
+#pragma unroll
+    for (int k = 0; k < N; k++) r[k] = __builtin_fma(r[k], f[k], r[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) f[k] = __builtin_fma(-d0[k], r[k], 1.0);
+#pragma unroll
+    for (int k = 0; k < N; k++) n1[k] = __builtin_amdgcn_div_scale(num[k], den[k], true, &fl[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) r[k] = __builtin_fma(r[k], f[k], r[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) mul[k] = n1[k] * r[k];
+#pragma unroll
+    for (int k = 0; k < N; k++) f[k] = __builtin_fma(-d0[k], mul[k], n1[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) q[k] = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(f[k], r[k], mul[k], fl[k]), den[k], num[k]);
 }
 // a wave-uniform double moved to scalar registers
 __device__ __forceinline__ double uniform_f64(double v) {
@@ -351,7 +384,7 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
     } while (0)
 // tableau wave: the lane that holds column q stores the wave's part of it in s.alpha, for the
 // control wave and for the wave itself: every lane reads it back (broadcast reads; a v_readlane
-// per value would cost ~10 cycles each); then one count on s.seq
+// per value would cost ~10 cycles each), after one count on s.seq
 #define MIPX_PUBLISH_COL(q_)                                                                \
     do {                                                                                    \
         const int ql_ = (q_) >> 6;                                                          \
@@ -360,12 +393,13 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
                 _Pragma("unroll") for (int ii = 0; ii < R; ii++) s.alpha[tw * RS + ii] = T[ii][jj]; \
             }                                                                               \
         }                                                                                   \
-        /* same wave, LDS executes in order: only the compiler must not move the reads up */ \
+        /* the count first: the control wave is waiting for it.  (The release orders the stores */ \
+        /* before it; same wave, LDS executes in order, so the reads below see them too.)       */ \
+        if (lane == 0) __hip_atomic_fetch_add(&s.seq, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                              \
         __builtin_amdgcn_wave_barrier();                                                    \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                              \
         _Pragma("unroll") for (int ii = 0; ii < R; ii++) al[ii] = s.alpha[tw * RS + ii];    \
-        if (lane == 0) __hip_atomic_fetch_add(&s.seq, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
     } while (0)
 // the control wave waits until all NW parts of the current pivot column are in s.alpha
 #define MIPX_AWAIT_COL(target_)                                                             \
@@ -576,8 +610,9 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
         for (int jj = 0; jj < C; jj++) T[ii][jj] = 0.0;
     }
     if (!ctl) {
-        // every load is issued unconditionally from a clamped address (all requests in flight at
-        // once, 512 contiguous bytes per wave instruction); the padding is zeroed afterwards
+        // The tableau first: its 256 KiB stream through the L1 while the border loads below wait
+        // for HBM.  Every load is issued unconditionally from a clamped address (512 contiguous
+        // bytes per wave instruction); sign and padding are fixed where the values are first used
         const double *tsrc = anchored ? g.anchor_T : gA;
         int joff[C];
 #pragma unroll
@@ -588,36 +623,41 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
 #pragma unroll
             for (int jj = 0; jj < C; jj++) T[ii][jj] = m > 0 ? arow[joff[jj]] : 0.0;
         }
-#pragma unroll
-        for (int ii = 0; ii < R; ii++) {
-#pragma unroll
-            for (int jj = 0; jj < C; jj++)
-                T[ii][jj] = (tw + NW * ii < m && lane + 64 * jj < n) ? sgn * T[ii][jj] : 0.0;
+    }
+    {
+        // borders: every global load of the stage is issued before the first one is consumed (one
+        // memory latency, not one per array); clamped addresses, the padding is fixed afterwards
+        static_assert(NT >= NP + MP, "one staging element per thread");
+        const int ic = min(tid, m > 0 ? m - 1 : 0), jc = min(tid, n - 1), vc = min(tid, nv - 1);
+        const double g_b0 = anchored ? g.anchor_vec[n + ic] : (m > 0 ? gb[ic] : 0.0);
+        const int g_bv = anchored ? g.anchor_idx[n + ic] : n + ic;
+        const double g_d = anchored ? g.anchor_vec[jc] : gc[jc];
+        const int g_nv = anchored ? g.anchor_idx[jc] : jc;
+        const double g_lo = lk[jc], g_up = uk[jc];
+        const int8_t g_st = vin ? vin[vc] : (int8_t)0;
+        if (tid < MP) {
+            s.beta0[tid] = tid < m ? (anchored ? g_b0 : -g_b0) : 0.0;
+            s.bvar[tid] = tid < m ? g_bv : -1;
+        }
+        if (tid < NP) {
+            s.d[tid] = tid < n ? g_d : 0.0;
+            s.nvar[tid] = tid < n ? g_nv : -1;
+            s.lo[tid] = tid < n ? g_lo : 0.0;
+            s.up[tid] = tid < n ? g_up : 0.0;
+            s.va[tid] = 0.0;
+            s.vb[tid] = 0.0;
+        }
+        if (tid < NP + MP) {
+            const int8_t st = tid < nv ? g_st : (int8_t)0;
+            s.wantb[tid] = st == 1;
+            s.atup[tid] = st == 2;
+            s.pos[tid] = -1;
         }
     }
-#pragma unroll 1
-    for (int i = tid; i < MP; i += NT) {
-        s.beta0[i] = i < m ? (anchored ? g.anchor_vec[n + i] : -gb[i]) : 0.0;
-        s.bvar[i] = i < m ? (anchored ? g.anchor_idx[n + i] : n + i) : -1;
-    }
-#pragma unroll 1
-    for (int j = tid; j < NP; j += NT) {
-        s.d[j] = j < n ? (anchored ? g.anchor_vec[j] : gc[j]) : 0.0;
-        s.nvar[j] = j < n ? (anchored ? g.anchor_idx[j] : j) : -1;
-        s.lo[j] = j < n ? lk[j] : 0.0;
-        s.up[j] = j < n ? uk[j] : 0.0;
-        s.va[j] = 0.0;
-        s.vb[j] = 0.0;
-    }
-#pragma unroll 1
-    for (int v = tid; v < NP + MP; v += NT) {
-        int8_t st = (vin && v < nv) ? vin[v] : (int8_t)0;
-        s.wantb[v] = st == 1;
-        s.atup[v] = st == 2;
-        s.pos[v] = -1;
-    }
     if (tid == 0) s.seq = 0;
+    KPROF_SETUP_MARK(9);
     __syncthreads();
+    KPROF_SETUP_MARK(10);
     for (int j = tid; j < NP; j += NT) {
         const int v = s.nvar[j];
         if (j < n) s.pos[v] = j;
@@ -625,6 +665,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
         s.meta[j] = (v << 3) | (fix ? 4 : 0);
     }
     __syncthreads();
+    KPROF_SETUP_MARK(12);
     if (tid < 64) {  // columns of the variables to pivot in, in ascending variable order
         int cnt = 0;
         for (int base = 0; base < nv; base += 64) {
@@ -656,8 +697,17 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
         rM[kk] = (v << 2) | ((v >= 0 && s.wantb[v < 0 ? 0 : v]) ? 1 : 0);
         aix[kk] = MIPX_AIDX(ic);
     }
+    KPROF_SETUP_MARK(13);
     __syncthreads();
     const int nw = __builtin_amdgcn_readfirstlane(s.nw);
+    if (!ctl) {  // the tableau loads land here: sign, and zeros in the padding
+#pragma unroll
+        for (int ii = 0; ii < R; ii++) {
+#pragma unroll
+            for (int jj = 0; jj < C; jj++)
+                T[ii][jj] = (tw + NW * ii < m && lane + 64 * jj < n) ? sgn * T[ii][jj] : 0.0;
+        }
+    }
 
     int npiv = 0, iters = 0, status = -1;
     const int cap = 100 * (m + n) + 1000;
@@ -865,24 +915,25 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
                 KPROF_MARK(1);
                 __syncthreads();  // B: row r is in s.row
                 // (c) Harris ratio test on row r
-                double aa[C], dje[C], rc[C];
+                double aa[C], dje[C], num[C], key[C];
                 bool el[C];
                 double k1 = INF;
                 int p1 = kNoCand;
                 const double tol = bland ? 0.0 : kDTol;  // Bland: the textbook ratio dj / |a|
 #pragma unroll
                 for (int kk = 0; kk < C; kk++) {
-                    const int j = lane + 64 * kk;
-                    const double rv = s.row[j];
+                    const double rv = s.row[lane + 64 * kk];
                     const double a = __hiloint2double(__double2hiint(rv) ^ sflip, __double2loint(rv));
                     const int sd = cM[kk] & 3;
                     el[kk] = ((cM[kk] & 4) == 0) & (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
                     dje[kk] = sd == 0 ? fmax(cD[kk], 0.0) : fmax(-cD[kk], 0.0);
                     aa[kk] = fabs(a);
-                    const double key = (dje[kk] + tol) / aa[kk];  // unconditionally: no divergent branch
-                    rc[kk] = 1.0 / rv;                            // 1/p of every candidate, likewise
-                    keep_min(k1, p1, key, ((cM[kk] >> 3) << 16) | j, el[kk]);
+                    num[kk] = dje[kk] + tol;
                 }
+                div_n<C>(num, aa, key);  // every column, unconditionally: no divergent branch
+#pragma unroll
+                for (int kk = 0; kk < C; kk++)
+                    keep_min(k1, p1, key[kk], ((cM[kk] >> 3) << 16) | (lane + 64 * kk), el[kk]);
                 double thmax;
                 const int w1 = wave_argmin_pos(k1, p1, thmax);
                 int qq = -1;
@@ -905,23 +956,21 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
                 int ev = 0;
                 if (qq >= 0) {
                     const int ql = qq & 63, qk = qq >> 6;
-                    double t0, t1;
+                    double t0;
                     int tm;
                     MIPX_PICK(t0, dje, C, qk);
-                    MIPX_PICK(t1, rc, C, qk);
                     MIPX_PICK(tm, cM, C, qk);
                     const double djq = readlane_f64(t0, ql);
                     const int cm = __builtin_amdgcn_readlane(tm, ql);
                     degen = djq <= kDTol ? degen + 1 : 0;
                     bland = degen > m + n;
                     nfk += ((lvmeta & 3) == 2 ? 1 : 0) - ((cm & 3) == 2 ? 1 : 0);
-                    pinv = readlane_f64(t1, ql);
                     ev = cm >> 3;
                     if (lane == 0) {
                         MailB mb;
                         mb.q = qq;
                         mb.ev = ev;
-                        mb.pinv = pinv;
+                        mb.pinv = 0.0;
                         s.mbB = mb;
                     }
                     vaq = uniform_f64(s.va[qq]);
@@ -933,6 +982,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
                 __syncthreads();  // C: column chosen
                 if (qq < 0) { status = 1; break; }  // no entering column: primal infeasible
                 const int q = qq;
+                pinv = 1.0 / uniform_f64(s.row[q]);  // 1/p: every wave works it out for itself
                 iters++;
                 npiv++;
                 cols++;
@@ -985,6 +1035,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
                 if (q < 0) break;
                 KPROF_MARK(8);
                 MIPX_PUBLISH_COL(q);  // (d)
+                pinv = 1.0 / uniform_f64(s.row[q]);  // 1/p: every wave works it out for itself
                 KPROF_MARK(4);
                 MIPX_UPDATE_T(r, q, pinv);
                 KPROF_MARK(5);

@@ -113,11 +113,11 @@ int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t strea
             fprintf(stderr, "[kprof] %s batch %d wave %d  lps %llu iters %llu refactor pivots %llu\n"
                     "  simplex cycles/iter: m1 %.0f m3 %.0f m2 %.0f m4 %.0f m5 %.0f m0 %.0f  (sum %.0f)\n"
                     "  refactor cycles/pivot: m9 %.0f m10 %.0f m12 %.0f m13 %.0f m14 %.0f  (sum %.0f)\n"
-                    "  per LP: setup %.0f m8/iter %.0f m11 %.0f value-init %.0f tail %.0f\n",
+                    "  per LP: setup %.0f m8/iter %.0f m11/iter %.0f value-init %.0f tail %.0f\n",
                     cfg->name, batch, a.prof_wave, h[18], h[16], h[17], h[1] / it, h[3] / it, h[2] / it,
                     h[4] / it, h[5] / it, h[0] / it, (h[0] + h[1] + h[2] + h[3] + h[4] + h[5]) / it,
                     h[9] / rf, h[10] / rf, h[12] / rf, h[13] / rf, h[14] / rf,
-                    (h[9] + h[10] + h[12] + h[13] + h[14]) / rf, h[15] / lps, h[8] / it, h[11] / lps,
+                    (h[9] + h[10] + h[12] + h[13] + h[14]) / rf, h[15] / lps, h[8] / it, h[11] / it,
                     h[7] / lps, h[6] / lps);
         }
         return MIPX_OK;

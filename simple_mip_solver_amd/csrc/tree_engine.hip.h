@@ -69,6 +69,75 @@ struct PyHeap {
     size_t size() const { return h.size(); }
 };
 
+// Open list of the batched best-first search (frontier batches > 1): a step takes the B smallest
+// keys at once, so per-node heap order is not needed.  Keys are bucketed linearly above the first
+// (smallest: a child's bound is never below its parent's) key; a step empties whole buckets in
+// key order and splits the last one exactly with nth_element.  O(1) pushes, O(B) per step, where
+// the binary heap paid ~0.1 us per push and pop in cache misses.
+struct BucketQueue {
+    struct Item { double key; int64_t id; };
+    static constexpr size_t kMaxBuckets = (size_t)1 << 22;
+    std::vector<std::vector<Item>> tab;
+    double k0 = 0.0, inv_width = 0.0;
+    size_t cur = 0, count = 0;
+    bool started = false;
+    size_t index(double key) const {
+        const double r = (key - k0) * inv_width;
+        if (!(r > 0.0)) return 0;
+        return r >= (double)(kMaxBuckets - 1) ? kMaxBuckets - 1 : (size_t)r;
+    }
+    void push(double key, int64_t id) {
+        if (!started && std::isfinite(key)) {  // (the root's inherited bound is -inf: bucket 0)
+            started = true;
+            k0 = key;
+            inv_width = 4096.0 / std::fmax(std::fabs(key), 1.0);  // bucket width: 2^-12 of |first key|
+        }
+        const size_t i = started ? index(key) : 0;
+        if (i >= tab.size()) tab.resize(i + 1 + (i >> 3));
+        tab[i].push_back({key, id});
+        if (count == 0 || i < cur) cur = i;
+        count++;
+    }
+    bool empty() const { return count == 0; }
+    size_t size() const { return count; }
+    void settle() { while (cur < tab.size() && tab[cur].empty()) cur++; }
+    double min_key() {
+        settle();
+        double k = std::numeric_limits<double>::infinity();
+        for (const Item &it : tab[cur]) k = std::fmin(k, it.key);
+        return k;
+    }
+    // the `want` smallest items (ties: smaller id first) are appended to out
+    void pop_batch(size_t want, std::vector<Item> &out) {
+        while (want > 0 && count > 0) {
+            settle();
+            std::vector<Item> &v = tab[cur];
+            if (v.size() <= want) {
+                out.insert(out.end(), v.begin(), v.end());
+                want -= v.size();
+                count -= v.size();
+                v.clear();
+            } else {
+                auto less = [](const Item &a, const Item &b) { return a.key < b.key || (a.key == b.key && a.id < b.id); };
+                std::nth_element(v.begin(), v.begin() + (std::ptrdiff_t)want, v.end(), less);
+                out.insert(out.end(), v.begin(), v.begin() + (std::ptrdiff_t)want);
+                v.erase(v.begin(), v.begin() + (std::ptrdiff_t)want);
+                count -= want;
+                want = 0;
+            }
+        }
+    }
+    // every item, in bucket order (for peek / sharding)
+    void items(std::vector<Item> &out) const {
+        for (size_t i = cur; i < tab.size(); i++) out.insert(out.end(), tab[i].begin(), tab[i].end());
+    }
+    void clear() {
+        for (auto &v : tab) v.clear();
+        count = 0;
+        cur = 0;
+    }
+};
+
 // Per-step device outputs and host staging, double-buffered so that the host bookkeeping of step
 // k overlaps the node-LP kernel of step k+1 (frontier batches > 1).
 struct StepBuf {
@@ -76,6 +145,11 @@ struct StepBuf {
             *d_bidx = nullptr, *d_mipf = nullptr, *d_nprobe = nullptr, *d_plist = nullptr;
     double *d_obj = nullptr, *d_x = nullptr, *d_bval = nullptr;
     int8_t *d_vout = nullptr;
+    // what the host reads back every step, packed so that ONE copy into pinned memory fetches it:
+    // [obj | bval] (f64) then [status | bidx | mipf | nprobe | npiv] (i32), max_batch entries each
+    char *d_pack = nullptr, *h_pack = nullptr;
+    size_t pack_bytes = 0;
+    int32_t *h_slot = nullptr;  // pinned staging of the batch's pool rows
     hipEvent_t e0 = nullptr, e1 = nullptr, done = nullptr;
     std::vector<int64_t> ids;
     std::vector<int32_t> slots, br_pos, br_slot, br_var, br_child;  // staging kept alive
@@ -97,6 +171,10 @@ struct mipx_tree {
     double *d_cost_l = nullptr, *d_cost_r = nullptr, *d_cost_l2 = nullptr, *d_cost_r2 = nullptr;
     uint8_t *d_has = nullptr, *d_has2 = nullptr;
     hipStream_t st2 = nullptr;  // strong-branching probes + re-scoring run beside the step in flight
+    hipStream_t st3 = nullptr;  // children records of step k are written beside the node LPs of step k+1
+    hipEvent_t ev_child = nullptr;
+    bool child_pending = false;
+    int32_t *h_pairs = nullptr; // pinned staging of the branching lists
     StepBuf buf[2];
     bool table_dirty = false, pipeline = true;
     // probe pool (strong branching)
@@ -107,7 +185,10 @@ struct mipx_tree {
     // host state
     std::vector<NodeRec> nodes;
     std::vector<int32_t> free_slots;
-    PyHeap heap;
+    PyHeap heap;        // exact mode (max_batch == 1) and depth-first search
+    BucketQueue bq;     // batched best-first search
+    bool use_bq = false;
+    std::vector<BucketQueue::Item> popped;
     std::priority_queue<std::pair<double, int64_t>, std::vector<std::pair<double, int64_t>>,
                         std::greater<std::pair<double, int64_t>>> open_bounds;  // lazy, for DFS
     std::vector<uint8_t> is_open;
@@ -140,6 +221,7 @@ int dmalloc(mipx_ctx *ctx, T **p, size_t count) {
 
 double tree_open_min(mipx_tree *t) {
     const double inf = std::numeric_limits<double>::infinity();
+    if (t->use_bq) return t->bq.empty() ? inf : t->bq.min_key();
     if (t->search == 0) return t->heap.empty() ? inf : t->heap.h[0].key;
     while (!t->open_bounds.empty() && !t->is_open[t->open_bounds.top().second]) t->open_bounds.pop();
     return t->open_bounds.empty() ? inf : t->open_bounds.top().first;
@@ -157,8 +239,22 @@ double tree_gap(mipx_tree *t) {
     return std::fabs(p - d) / std::fabs(p);
 }
 
+bool tree_queue_empty(const mipx_tree *t) { return t->use_bq ? t->bq.empty() : t->heap.empty(); }
+
+// open nodes in queue order (heap array order / bucket order)
+void tree_queue_ids(const mipx_tree *t, std::vector<int64_t> &out) {
+    if (t->use_bq) {
+        std::vector<BucketQueue::Item> items;
+        t->bq.items(items);
+        for (const auto &it : items) out.push_back(it.id);
+    } else {
+        for (const auto &it : t->heap.h) out.push_back(it.id);
+    }
+}
+
 void tree_push(mipx_tree *t, int64_t id) {
-    t->heap.push(t->nodes[id].key, id);
+    if (t->use_bq) t->bq.push(t->nodes[id].key, id);
+    else t->heap.push(t->nodes[id].key, id);
     if ((size_t)id >= t->is_open.size()) t->is_open.resize(id + 1, 0);
     t->is_open[id] = 1;
     if (t->search != 0) t->open_bounds.push({t->nodes[id].dual_bound, id});
@@ -223,18 +319,26 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
     slots.clear();
     S.B = 0;
     S.in_flight = false;
-    while ((int)ids.size() < want && !t->heap.empty()) {
-        const int64_t id = t->heap.pop();
+    auto take = [&](int64_t id) {
         t->is_open[id] = 0;
         NodeRec &nd = t->nodes[id];
         if (!(nd.dual_bound < t->primal)) {
             t->closed_min = std::fmin(t->closed_min, nd.dual_bound);
             t->free_slots.push_back(nd.slot);
             nd.slot = -1;
-            continue;
+            return;
         }
         ids.push_back(id);
         slots.push_back(nd.slot);
+    };
+    if (t->use_bq) {
+        while ((int)ids.size() < want && !t->bq.empty()) {
+            t->popped.clear();
+            t->bq.pop_batch((size_t)want - ids.size(), t->popped);
+            for (const BucketQueue::Item &it : t->popped) take(it.id);
+        }
+    } else {
+        while ((int)ids.size() < want && !tree_queue_empty(t)) take(t->heap.pop());
     }
     const int B = (int)ids.size();
     if (B == 0) return MIPX_OK;
@@ -249,8 +353,13 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
         HIP_TRY(ctx, hipMemcpyAsync(t->d_has, t->has_entry.data(), n, hipMemcpyHostToDevice, st));
         t->table_dirty = false;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(S.d_slot, slots.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    // 2. LP relaxations + scoring
+    std::memcpy(S.h_slot, slots.data(), (size_t)B * 4);
+    HIP_TRY(ctx, hipMemcpyAsync(S.d_slot, S.h_slot, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    // 2. LP relaxations + scoring (after the children records of the last finished step)
+    if (t->child_pending) {
+        HIP_TRY(ctx, hipStreamWaitEvent(st, t->ev_child, 0));
+        t->child_pending = false;
+    }
     HIP_TRY(ctx, hipEventRecord(S.e0, st));
     int rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, S.d_slot, 0, S.d_status, S.d_obj,
                        S.d_x, S.d_vout, S.d_iters, S.d_npiv);
@@ -278,20 +387,17 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     const std::vector<int64_t> &ids = S.ids;
     const std::vector<int32_t> &slots = S.slots;
     int rc = MIPX_OK;
-    std::vector<int32_t> status(B), bidx(B), mipf(B), nprobe(B), npiv(B);
-    std::vector<double> obj(B), bval(B);
     HIP_TRY(ctx, hipEventSynchronize(S.done));
     {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, S.e0, S.e1) == hipSuccess) t->kernel_ms += ms;
     }
-    HIP_TRY(ctx, hipMemcpy(status.data(), S.d_status, (size_t)B * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(obj.data(), S.d_obj, (size_t)B * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(bidx.data(), S.d_bidx, (size_t)B * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(bval.data(), S.d_bval, (size_t)B * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(mipf.data(), S.d_mipf, (size_t)B * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(nprobe.data(), S.d_nprobe, (size_t)B * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(npiv.data(), S.d_npiv, (size_t)B * 4, hipMemcpyDeviceToHost));
+    // one copy (pinned destination) for everything the host reads per node
+    HIP_TRY(ctx, hipMemcpy(S.h_pack, S.d_pack, S.pack_bytes, hipMemcpyDeviceToHost));
+    const size_t MB = (size_t)t->max_batch;
+    double *obj = (double *)S.h_pack, *bval = obj + MB;
+    int32_t *status = (int32_t *)(bval + MB), *bidx = status + MB, *mipf = bidx + MB, *nprobe = mipf + MB,
+            *npiv = nprobe + MB;
     t->lps += B;
     for (int k = 0; k < B; k++) t->pivots += npiv[k];
     t->phase_ms[1] += ms_since(tp); tp = now();
@@ -369,6 +475,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             HIP_TRY(ctx, hipMemcpy(pobj.data(), t->pp_obj, pobj.size() * 8, hipMemcpyDeviceToHost));
             t->probes += 2 * P;
         }
+        t->phase_ms[5] += ms_since(tp); tp = now();
         // table updates in the reference's order: node by node; per node its probes (ascending
         // integer index, left then right), then its own branch unless just initialised
         size_t e = 0;
@@ -401,6 +508,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         // re-score with the updated table: always in the sequential mode (the reference branches
         // with the table its own node just updated); when steps overlap, only if probes created
         // entries that the first scoring had to leave out (the wait covers the step in flight)
+        t->phase_ms[6] += ms_since(tp); tp = now();
         if (changed && (!overlapped || total > 0)) {
             double *cl = use_side ? t->d_cost_l2 : t->d_cost_l, *cr = use_side ? t->d_cost_r2 : t->d_cost_r;
             uint8_t *ch = use_side ? t->d_has2 : t->d_has;
@@ -410,8 +518,8 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             if (!use_side) t->table_dirty = false;
             if ((rc = launch_score(t, S, B, use_side))) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ps));
-            HIP_TRY(ctx, hipMemcpy(bidx.data(), S.d_bidx, (size_t)B * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(ctx, hipMemcpy(bval.data(), S.d_bval, (size_t)B * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(bidx, S.d_bidx, (size_t)B * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(bval, S.d_bval, (size_t)B * 8, hipMemcpyDeviceToHost));
         }
     }
 
@@ -477,10 +585,15 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     // 5. children records on the device, then release the evaluated nodes' rows
     const int P = (int)br_pos.size();
     if (P > 0) {
-        HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs, br_slot.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs + P, br_pos.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs + 2 * P, br_var.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs + 3 * P, br_child.data(), (size_t)P * 8, hipMemcpyHostToDevice, st));
+        // when steps overlap this runs on its own stream, beside the node LPs of the step in flight
+        // (it writes fresh pool rows only); the next launch waits for it
+        hipStream_t cs = overlapped ? t->st3 : st;
+        if (overlapped) HIP_TRY(ctx, hipStreamSynchronize(t->st3));  // h_pairs / d_pairs free again
+        std::memcpy(t->h_pairs, br_slot.data(), (size_t)P * 4);
+        std::memcpy(t->h_pairs + P, br_pos.data(), (size_t)P * 4);
+        std::memcpy(t->h_pairs + 2 * P, br_var.data(), (size_t)P * 4);
+        std::memcpy(t->h_pairs + 3 * P, br_child.data(), (size_t)P * 8);
+        HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs, t->h_pairs, (size_t)P * 20, hipMemcpyHostToDevice, cs));
         mipx::ChildArgs ca;
         ca.n = n; ca.m = t->m; ca.count = P;
         ca.src_l = t->pool_l; ca.src_u = t->pool_u;
@@ -488,9 +601,14 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         ca.x = S.d_x; ca.vstat = S.d_vout;
         ca.dst_l = t->pool_l; ca.dst_u = t->pool_u; ca.dst_v = t->pool_v;
         ca.child_slot = t->d_pairs + 3 * P;
-        hipLaunchKernelGGL(mipx::make_children, dim3(2 * P), dim3(256), 0, st, ca);
+        hipLaunchKernelGGL(mipx::make_children, dim3(2 * P), dim3(256), 0, cs, ca);
         HIP_TRY(ctx, hipGetLastError());
-        if (!overlapped) HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (overlapped) {
+            HIP_TRY(ctx, hipEventRecord(t->ev_child, t->st3));
+            t->child_pending = true;
+        } else {
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+        }
     }
     for (int k = 0; k < B; k++) {
         t->free_slots.push_back(slots[k]);
@@ -520,6 +638,7 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     t->prob = p; t->ctx = ctx; t->n = p->n; t->m = p->m; t->n_int = n_int;
     t->rule = branch_rule; t->search = search_rule; t->sb_iters = strong_branch_iters;
     t->max_batch = max_batch;
+    t->use_bq = max_batch > 1 && search_rule == 0;
     t->capacity = pool_capacity > 2 * (int64_t)max_batch + 2 ? pool_capacity : 2 * (int64_t)max_batch + 2;
     t->int_idx.assign(int_idx, int_idx + n_int);
     for (int i = 0; i < n_int; i++)
@@ -536,14 +655,24 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     rc |= dmalloc(ctx, &t->d_pairs2, 5 * (pc / 2 > B ? pc / 2 : B));
     rc |= dmalloc(ctx, &t->d_cost_l2, n); rc |= dmalloc(ctx, &t->d_cost_r2, n); rc |= dmalloc(ctx, &t->d_has2, n);
     if (hipStreamCreateWithFlags(&t->st2, hipStreamNonBlocking) != hipSuccess) rc |= MIPX_EHIP;
+    if (hipStreamCreateWithFlags(&t->st3, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&t->ev_child, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void **)&t->h_pairs, 5 * B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
     for (StepBuf &S : t->buf) {
-        rc |= dmalloc(ctx, &S.d_slot, B); rc |= dmalloc(ctx, &S.d_status, B);
-        rc |= dmalloc(ctx, &S.d_iters, B); rc |= dmalloc(ctx, &S.d_npiv, B);
-        rc |= dmalloc(ctx, &S.d_bidx, B); rc |= dmalloc(ctx, &S.d_mipf, B);
-        rc |= dmalloc(ctx, &S.d_nprobe, B);
+        rc |= dmalloc(ctx, &S.d_slot, B);
+        rc |= dmalloc(ctx, &S.d_iters, B);
+        S.pack_bytes = B * (2 * 8 + 5 * 4);
+        rc |= dmalloc(ctx, &S.d_pack, S.pack_bytes);
+        if (hipHostMalloc((void **)&S.h_pack, S.pack_bytes, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&S.h_slot, B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
+        if (S.d_pack) {
+            S.d_obj = (double *)S.d_pack; S.d_bval = S.d_obj + B;
+            S.d_status = (int32_t *)(S.d_bval + B); S.d_bidx = S.d_status + B; S.d_mipf = S.d_bidx + B;
+            S.d_nprobe = S.d_mipf + B; S.d_npiv = S.d_nprobe + B;
+        }
         rc |= dmalloc(ctx, &S.d_plist, B * (size_t)(n_int ? n_int : 1));
-        rc |= dmalloc(ctx, &S.d_obj, B); rc |= dmalloc(ctx, &S.d_x, B * n);
-        rc |= dmalloc(ctx, &S.d_bval, B); rc |= dmalloc(ctx, &S.d_vout, B * nv);
+        rc |= dmalloc(ctx, &S.d_x, B * n);
+        rc |= dmalloc(ctx, &S.d_vout, B * nv);
         if (hipEventCreate(&S.e0) != hipSuccess || hipEventCreate(&S.e1) != hipSuccess ||
             hipEventCreate(&S.done) != hipSuccess) rc |= MIPX_EHIP;
     }
@@ -587,15 +716,19 @@ void mipx_tree_destroy(mipx_tree *t) {
     if (t->ctx) (void)hipSetDevice(t->ctx->device);
     if (t->ctx && t->ctx->stream) (void)hipStreamSynchronize(t->ctx->stream);
     if (t->st2) { (void)hipStreamSynchronize(t->st2); (void)hipStreamDestroy(t->st2); }
+    if (t->st3) { (void)hipStreamSynchronize(t->st3); (void)hipStreamDestroy(t->st3); }
+    if (t->ev_child) (void)hipEventDestroy(t->ev_child);
+    if (t->h_pairs) (void)hipHostFree(t->h_pairs);
     void *ptrs[] = {t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_pairs, t->d_pairs2, t->d_cost_l,
                     t->d_cost_r, t->d_has, t->d_cost_l2, t->d_cost_r2, t->d_has2, t->pp_l, t->pp_u, t->pp_v, t->pp_obj, t->pp_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (StepBuf &S : t->buf) {
-        void *sp[] = {S.d_slot, S.d_status, S.d_iters, S.d_npiv, S.d_bidx, S.d_mipf, S.d_nprobe,
-                      S.d_plist, S.d_obj, S.d_x, S.d_bval, S.d_vout};
+        void *sp[] = {S.d_slot, S.d_iters, S.d_pack, S.d_plist, S.d_x, S.d_vout};
         for (void *q : sp)
             if (q) (void)hipFree(q);
+        if (S.h_pack) (void)hipHostFree(S.h_pack);
+        if (S.h_slot) (void)hipHostFree(S.h_slot);
         if (S.e0) (void)hipEventDestroy(S.e0);
         if (S.e1) (void)hipEventDestroy(S.e1);
         if (S.done) (void)hipEventDestroy(S.done);
@@ -633,6 +766,9 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const auto t0 = std::chrono::steady_clock::now();
     const double inf = std::numeric_limits<double>::infinity();
+    double ph0[8];
+    for (int k = 0; k < 8; k++) ph0[k] = t->phase_ms[k];
+    const double k0 = t->kernel_ms;
     if (!t->started) {
         t->started = true;
         tree_push(t, 0);
@@ -658,14 +794,14 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
             want = (int)(node_limit - t->evaluated - inflight);
         return want;
     };
-    if (!t->heap.empty() && !stop_now(0)) {
+    if (!tree_queue_empty(t) && !stop_now(0)) {
         int rc = tree_launch(t, t->buf[cur], batch_size(0));
         if (rc) return rc;
         if (t->buf[cur].in_flight) steps++;
     }
     while (t->buf[cur].in_flight) {
         StepBuf &S = t->buf[cur], &N = t->buf[1 - cur];
-        if (overlap && !t->heap.empty() && !stop_now(S.B)) {
+        if (overlap && !tree_queue_empty(t) && !stop_now(S.B)) {
             const int want = batch_size(S.B);
             if (want > 0) {
                 int rc = tree_launch(t, N, want);
@@ -675,18 +811,27 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
         }
         int rc = tree_finish(t, S, overlap);
         if (rc) return rc;
-        if (!N.in_flight && !t->heap.empty() && !stop_now(0)) {
+        if (!N.in_flight && !tree_queue_empty(t) && !stop_now(0)) {
             rc = tree_launch(t, N, batch_size(0));
             if (rc) return rc;
             if (N.in_flight) steps++;
         }
         cur = 1 - cur;
     }
+    HIP_TRY(ctx, hipStreamSynchronize(t->st3));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     t->solve_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (std::getenv("MIPX_TREE_PROFILE")) {
+        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::fprintf(stderr, "[mipx_tree] call: %lld steps in %.2f ms | pop %.2f  wait+d2h %.2f  pseudo-cost %.2f  "
+                     "bookkeeping %.2f  children %.2f | lp kernel %.2f | pc: probes %.2f updates %.2f rescoring %.2f\n", (long long)steps, wall,
+                     t->phase_ms[0] - ph0[0], t->phase_ms[1] - ph0[1], t->phase_ms[2] - ph0[2] + t->phase_ms[5] - ph0[5] + t->phase_ms[6] - ph0[6],
+                     t->phase_ms[3] - ph0[3], t->phase_ms[4] - ph0[4], t->kernel_ms - k0,
+                     t->phase_ms[5] - ph0[5], t->phase_ms[6] - ph0[6], t->phase_ms[2] - ph0[2]);
+    }
     const double gap = tree_gap(t);
     if (t->unbounded) t->status = 3;
-    else if (t->heap.empty() && t->primal == inf) t->status = 2;
+    else if (tree_queue_empty(t) && t->primal == inf) t->status = 2;
     else if (t->primal < inf && gap >= 0 && gap <= mip_gap) t->status = 1;
     else t->status = 4;
     if (out) return mipx_tree_get_stats(t, out);
@@ -699,7 +844,7 @@ int mipx_tree_get_stats(mipx_tree *t, mipx_tree_stats *out) {
     out->lp_solved = t->lps;
     out->probes_solved = t->probes;
     out->pivots = t->pivots;
-    out->open_nodes = (int64_t)t->heap.size();
+    out->open_nodes = (int64_t)(t->use_bq ? t->bq.size() : t->heap.size());
     out->created_nodes = (int64_t)t->nodes.size();
     out->steps = t->steps;
     out->primal_bound = t->primal;
@@ -738,8 +883,10 @@ int64_t mipx_tree_peek_open(mipx_tree *t, int64_t max_nodes, double *l, double *
     const size_t n = t->n, nv = t->n + t->m;
     int64_t k = 0;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return MIPX_EHIP;
-    for (size_t pos = 0; pos < t->heap.h.size() && k < max_nodes; pos++, k++) {
-        const NodeRec &nd = t->nodes[t->heap.h[pos].id];
+    std::vector<int64_t> order;
+    tree_queue_ids(t, order);
+    for (size_t pos = 0; pos < order.size() && k < max_nodes; pos++, k++) {
+        const NodeRec &nd = t->nodes[order[pos]];
         const size_t s = (size_t)nd.slot;
         if (l && hipMemcpy(l + k * n, t->pool_l + s * n, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
         if (u && hipMemcpy(u + k * n, t->pool_u + s * n, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
@@ -755,11 +902,13 @@ int64_t mipx_tree_peek_open(mipx_tree *t, int64_t max_nodes, double *l, double *
  * ranks of mipx_tree_stats.dual_bound. */
 int mipx_tree_keep_shard(mipx_tree *t, int rank, int world) {
     if (!t || world < 1 || rank < 0 || rank >= world) return MIPX_EINVAL;
-    std::vector<PyHeap::Item> old;
-    old.swap(t->heap.h);
+    std::vector<int64_t> old;
+    tree_queue_ids(t, old);
+    t->heap.h.clear();
+    t->bq.clear();
     while (!t->open_bounds.empty()) t->open_bounds.pop();
     for (size_t pos = 0; pos < old.size(); pos++) {
-        const int64_t id = old[pos].id;
+        const int64_t id = old[pos];
         t->is_open[id] = 0;
         if ((int)(pos % (size_t)world) == rank) {
             tree_push(t, id);
