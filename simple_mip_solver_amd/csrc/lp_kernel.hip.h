@@ -218,34 +218,6 @@ __device__ __forceinline__ int wave_argmin_pos(double key, int payload, double &
     kmin = __hiloint2double((int)hm, (int)lm);
     return wave_pick(valid & (hi == hm) & (lo == lm), payload);
 }
-// N independent f64 divisions num/den, written step by step across the N so that the N dependent
-// chains (12 instructions each) overlap; the sequence is the standard correctly-rounded one
-// (v_div_scale / v_rcp / fma refinement / v_div_fmas / v_div_fixup), i.e. bit-identical to '/'.
-template <int N>
-__device__ __forceinline__ void div_n(const double (&num)[N], const double (&den)[N], double (&q)[N]) {
-    double d0[N], r[N], f[N], n1[N], mul[N];
-    bool fl[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) { bool t; d0[k] = __builtin_amdgcn_div_scale(num[k], den[k], false, &t); }
-#pragma unroll
-    for (int k = 0; k < N; k++) r[k] = __builtin_amdgcn_rcp(d0[k]);
-#pragma unroll
-    for (int k = 0; k < N; k++) f[k] = __builtin_fma(-d0[k], r[k], 1.0);
-#pragma unroll
-    for (int k = 0; k < N; k++) r[k] = __builtin_fma(r[k], f[k], r[k]);
-#pragma unroll
-    for (int k = 0; k < N; k++) f[k] = __builtin_fma(-d0[k], r[k], 1.0);
-#pragma unroll
-    for (int k = 0; k < N; k++) n1[k] = __builtin_amdgcn_div_scale(num[k], den[k], true, &fl[k]);
-#pragma unroll
-    for (int k = 0; k < N; k++) r[k] = __builtin_fma(r[k], f[k], r[k]);
-#pragma unroll
-    for (int k = 0; k < N; k++) mul[k] = n1[k] * r[k];
-#pragma unroll
-    for (int k = 0; k < N; k++) f[k] = __builtin_fma(-d0[k], mul[k], n1[k]);
-#pragma unroll
-    for (int k = 0; k < N; k++) q[k] = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(f[k], r[k], mul[k], fl[k]), den[k], num[k]);
-}
 // a wave-uniform double moved to scalar registers
 __device__ __forceinline__ double uniform_f64(double v) {
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -915,25 +887,23 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
                 KPROF_MARK(1);
                 __syncthreads();  // B: row r is in s.row
                 // (c) Harris ratio test on row r
-                double aa[C], dje[C], num[C], key[C];
+                double aa[C], dje[C];
                 bool el[C];
                 double k1 = INF;
                 int p1 = kNoCand;
                 const double tol = bland ? 0.0 : kDTol;  // Bland: the textbook ratio dj / |a|
 #pragma unroll
                 for (int kk = 0; kk < C; kk++) {
-                    const double rv = s.row[lane + 64 * kk];
+                    const int j = lane + 64 * kk;
+                    const double rv = s.row[j];
                     const double a = __hiloint2double(__double2hiint(rv) ^ sflip, __double2loint(rv));
                     const int sd = cM[kk] & 3;
                     el[kk] = ((cM[kk] & 4) == 0) & (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
                     dje[kk] = sd == 0 ? fmax(cD[kk], 0.0) : fmax(-cD[kk], 0.0);
                     aa[kk] = fabs(a);
-                    num[kk] = dje[kk] + tol;
+                    const double key = (dje[kk] + tol) / aa[kk];  // unconditionally: no divergent branch
+                    keep_min(k1, p1, key, ((cM[kk] >> 3) << 16) | j, el[kk]);
                 }
-                div_n<C>(num, aa, key);  // every column, unconditionally: no divergent branch
-#pragma unroll
-                for (int kk = 0; kk < C; kk++)
-                    keep_min(k1, p1, key[kk], ((cM[kk] >> 3) << 16) | (lane + 64 * kk), el[kk]);
                 double thmax;
                 const int w1 = wave_argmin_pos(k1, p1, thmax);
                 int qq = -1;
