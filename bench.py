@@ -53,6 +53,7 @@ def main():
     ap.add_argument('--cons', type=int, default=128)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--cpu-threads', type=int, default=16, help='threads of the CPU baseline (over nodes)')
     ap.add_argument('--exchange-every', type=int, default=5, help='steps between all-reduces (N > 1)')
     ap.add_argument('--no-anchor', action='store_true',
                     help='refactor every node from the slack basis instead of the root tableau')
@@ -62,16 +63,23 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist, device = None, 'cpu'
+    gpu_index = local_rank
     if world > 1:
         import torch
         import torch.distributed as dist_
         dist = dist_
-        torch.cuda.set_device(local_rank)
-        device = torch.device('cuda', local_rank)
-        dist.init_process_group('nccl', device_id=device)
+        if os.environ.get('MIPX_BENCH_BACKEND') == 'gloo':
+            # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks: the ranks
+            # share the GPUs that exist and exchange over gloo (never a measurement)
+            gpu_index = local_rank % max(1, _ffi.lib().mipx_device_count())
+            dist.init_process_group('gloo')
+        else:
+            torch.cuda.set_device(local_rank)
+            device = torch.device('cuda', local_rank)
+            dist.init_process_group('nccl', device_id=device)
 
     n, m, B = args.vars, args.cons, args.batch
-    ctx = _ffi.Context(local_rank)
+    ctx = _ffi.Context(gpu_index)
     A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=args.seed)
     prob = _ffi.Problem(ctx, A, b, c)
     tree = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', search_rule='best first',
@@ -96,8 +104,9 @@ def main():
     def barrier():
         ctx.sync()
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
+            if device != 'cpu':
+                import torch
+                torch.cuda.synchronize()
             dist.barrier()
 
     if args.warmup > 0:
@@ -107,18 +116,44 @@ def main():
     cpu = None
     if rank == 0 and args.cpu_seconds > 0:
         from oracle import oracle as O
-        L, U, V, _ = tree.peek_open(4 * B)
-        done, t_cpu, chunk = 0, 0.0, 256
-        while t_cpu < args.cpu_seconds and done < len(L):
-            e0 = min(done + chunk, len(L))
-            tc = time.perf_counter()
-            O.lp_solve_batch(A, b, c, L[done:e0], U[done:e0], V[done:e0])
-            t_cpu += time.perf_counter() - tc
-            done = e0
-        cpu = {'value': done / t_cpu, 'unit': 'node LP-relaxations/s', 'cores': 1, 'kind': 'port',
+        from concurrent.futures import ThreadPoolExecutor
+        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+        L, U, V, _ = tree.peek_open(4 * B * (3 if threads > 4 else 1))
+        chunk = 128
+        nchunks = (len(L) + chunk - 1) // chunk
+        deadline = time.perf_counter() + args.cpu_seconds
+        done_chunks = []
+
+        def work(ci):  # ctypes releases the GIL inside the C oracle: the threads run in parallel
+            if time.perf_counter() > deadline:
+                return 0
+            e0 = min((ci + 1) * chunk, len(L))
+            O.lp_solve_batch(A, b, c, L[ci * chunk:e0], U[ci * chunk:e0], V[ci * chunk:e0])
+            return e0 - ci * chunk
+
+        # like the GPU path, warm starts refactor from the root's optimal tableau when anchoring is on
+        import contextlib
+        anchor_cm = contextlib.nullcontext()
+        if not args.no_anchor:
+            root = O.lp_solve(A, b, c, l, u)
+            anchor_cm = O.anchored(O.make_anchor(A, b, c, root['vstat']))
+        deadline = time.perf_counter() + args.cpu_seconds
+        tc = time.perf_counter()
+        with anchor_cm, ThreadPoolExecutor(threads) as ex:
+            done_chunks = list(ex.map(work, range(nchunks)))
+        t_cpu = time.perf_counter() - tc
+        done = int(sum(done_chunks))
+        model = ''
+        try:
+            model = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
+        except Exception:
+            pass
+        cpu = {'value': done / t_cpu, 'unit': 'node LP-relaxations/s', 'cores': threads, 'kind': 'port',
                'sample': f'{done} open nodes of the same tree (the LPs the GPU solves next: bounds + '
-                         f'warm-start bases read back from the device pool), '
-                         f'oracle/libmipx_oracle.so single thread, {t_cpu:.1f} s'}
+                         f'warm-start bases read back from the device pool), oracle/libmipx_oracle.so '
+                         f'({"anchored at the root tableau like the GPU path" if not args.no_anchor else "slack-basis refactorisation"}), '
+                         f'{threads} threads over nodes, {t_cpu:.1f} s wall; host: {os.cpu_count()} logical '
+                         f'CPUs, {model}'}
 
     # time-to-optimal leg of the metric: the 256x128 tree cannot be closed in a bench run, so the
     # same engine solves a small instance of the same family to proven optimality (rank 0, untimed
