@@ -20,8 +20,8 @@ constexpr int kBigMaxM = 1024;
 
 __host__ __device__ inline size_t big_lds_bytes(int m, int n) {
     const size_t dbl = (size_t)n * 10 + (size_t)m * 4 + 8;   // row d va vb lo up key aabs dje x | alpha beta0 ba bb | cd
-    const size_t i32 = (size_t)n * 3 + (size_t)m + 8;        // nvar side wlist | bvar | nw ci
-    const size_t i8 = 2 * (size_t)(n + m);
+    const size_t i32 = (size_t)n * 3 + (size_t)m + 8 + (size_t)(n + m);  // nvar side wlist | bvar | nw ci | pos
+    const size_t i8 = 2 * (size_t)(n + m) + (size_t)m;       // wantb atup | entered
     return dbl * 8 + i32 * 4 + i8 + 64;
 }
 
@@ -43,7 +43,8 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
     double *s_cd = s_bb + m;
     int *s_nvar = (int *)(s_cd + 8), *s_side = s_nvar + n, *s_wlist = s_side + n, *s_bvar = s_wlist + n;
     int *s_ci = s_bvar + m;             // [0..3] control words, [4] nw
-    int8_t *s_wantb = (int8_t *)(s_ci + 8), *s_atup = s_wantb + nv;
+    int *s_pos = s_ci + 8;              // column of each variable in the starting tableau, -1 if basic
+    int8_t *s_wantb = (int8_t *)(s_pos + nv), *s_atup = s_wantb + nv, *s_entered = s_atup + nv;
     double *T = scratch + (size_t)blockIdx.x * (size_t)m * n;
 
     for (int node = blockIdx.x; node < g.batch; node += gridDim.x) {
@@ -53,25 +54,39 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
         const double *gc = g.c + (size_t)node * g.c_stride;
         const double *lk = g.l + src * n, *uk = g.u + src * n;
         const int8_t *vin = g.vstat_in ? g.vstat_in + src * nv : nullptr;
-        // ---- 0. T = -A, beta0 = -b, d = c, slack basis --------------------------------------
-        for (size_t e = tid; e < (size_t)m * n; e += NT) T[e] = -gA[e];
-        for (int i = tid; i < m; i += NT) { s_beta0[i] = -gb[i]; s_bvar[i] = n + i; s_ba[i] = 0.0; s_bb[i] = 0.0; }
+        // ---- 0. T = -A, beta0 = -b, d = c, slack basis (or the anchor's tableau state) -------
+        const bool anchored = g.anchor_T != nullptr && vin != nullptr;
+        if (anchored) {
+            for (size_t e = tid; e < (size_t)m * n; e += NT) T[e] = g.anchor_T[e];
+        } else {
+            for (size_t e = tid; e < (size_t)m * n; e += NT) T[e] = -gA[e];
+        }
+        for (int i = tid; i < m; i += NT) {
+            s_beta0[i] = anchored ? g.anchor_vec[n + i] : -gb[i];
+            s_bvar[i] = anchored ? g.anchor_idx[n + i] : n + i;
+            s_ba[i] = 0.0; s_bb[i] = 0.0; s_entered[i] = 0;
+        }
         for (int j = tid; j < n; j += NT) {
-            s_d[j] = gc[j]; s_nvar[j] = j; s_lo[j] = lk[j]; s_up[j] = uk[j];
+            s_d[j] = anchored ? g.anchor_vec[j] : gc[j];
+            s_nvar[j] = anchored ? g.anchor_idx[j] : j;
+            s_lo[j] = lk[j]; s_up[j] = uk[j];
             s_side[j] = 0; s_va[j] = 0.0; s_vb[j] = 0.0;
         }
         for (int v = tid; v < nv; v += NT) {
             const int8_t st = vin ? vin[v] : (int8_t)0;
             s_wantb[v] = st == 1; s_atup[v] = st == 2;
+            s_pos[v] = -1;
         }
         __syncthreads();
-        if (tid < 64) {
+        for (int j = tid; j < n; j += NT) s_pos[s_nvar[j]] = j;
+        __syncthreads();
+        if (tid < 64) {  // columns of the variables to pivot in, in ascending variable order
             int cnt = 0;
-            for (int base = 0; base < n; base += 64) {
-                const int j = base + lane;
-                const bool w = j < n && s_wantb[j];
+            for (int base = 0; base < nv; base += 64) {
+                const int v = base + lane;
+                const bool w = v < nv && s_wantb[v] && s_pos[v] >= 0;
                 const unsigned long long mask = __ballot(w);
-                if (w) s_wlist[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+                if (w) s_wlist[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = s_pos[v];
                 cnt += __popcll(mask);
             }
             if (lane == 0) s_ci[4] = cnt;
@@ -86,7 +101,11 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
             int r = 0, q = 0, sigma = 1, newside = 0;
             double la = 0.0, lb = 0.0, pinv = 0.0;
             if (phase == 0) {
-                if (w >= nw) { phase = 1; continue; }
+                if (w >= nw) {
+                    if (g.refactor_only) { status = 3; break; }
+                    phase = 1;
+                    continue;
+                }
                 q = __builtin_amdgcn_readfirstlane(s_wlist[w]);
                 w++;
                 for (int i = tid; i < m; i += NT) s_alpha[i] = T[(size_t)i * n + q];
@@ -97,12 +116,12 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
 #pragma unroll 1
                     for (int kk = 0; kk < PIr; kk++) {
                         const int i = lane + 64 * kk;
-                        if (i < m) {
-                            const int bv = s_bvar[i];
+                        if (i < m) {  // rows whose basic variable is not wanted; else wanted, not yet pivoted in
+                            const bool wanted = s_wantb[s_bvar[i]];
                             const double a = fabs(s_alpha[i]);
-                            const bool ok = bv >= n && a > kPivTol;
-                            keep(k2, p2, a, i, ok);
-                            keep(k1, p1, a, i, ok && !s_wantb[bv >= n ? bv : n]);
+                            const bool ok = a > kPivTol;
+                            keep(k1, p1, a, i, ok && !wanted);
+                            keep(k2, p2, a, i, ok && wanted && !s_entered[i]);
                         }
                     }
                     double km;
@@ -327,7 +346,10 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                         s_d[j] = fma(-dq, s_row[j] * pinv, s_d[j]);
                     }
                 }
-                if (tid == NT - 1) { const int tmp = s_bvar[r]; s_bvar[r] = s_nvar[q]; s_nvar[q] = tmp; }
+                if (tid == NT - 1) {
+                    const int tmp = s_bvar[r]; s_bvar[r] = s_nvar[q]; s_nvar[q] = tmp;
+                    if (!vals) s_entered[r] = 1;
+                }
             }
             __syncthreads();
             npiv++;

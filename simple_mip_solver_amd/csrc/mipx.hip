@@ -320,8 +320,6 @@ int mipx_problem_set_anchor(mipx_problem *p, const int8_t *vstat) {
     if (!p) return MIPX_EINVAL;
     mipx_ctx *ctx = p->ctx;
     if (!vstat) { p->anchor_on = false; return MIPX_OK; }
-    const KernelCfg *cfg = pick_cfg(p->m, p->n);
-    if (!cfg) return fail(ctx, MIPX_ETOOBIG, "mipx_problem_set_anchor: only for the register-resident tiles");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t m = p->m ? p->m : 1, n = p->n, nv = n + p->m;
     if (!p->anchor_T) {
@@ -344,11 +342,11 @@ int mipx_problem_set_anchor(mipx_problem *p, const int8_t *vstat) {
     a.status = nullptr; a.obj = nullptr; a.x = nullptr; a.y = nullptr; a.vstat_out = nullptr;
     a.iters = nullptr; a.npivots = nullptr; a.batch = 1;
     a.dbg_T = p->anchor_T; a.dbg_vec = p->anchor_vec; a.dbg_idx = p->anchor_idx; a.dbg_all = 0;
-    cfg->launch(a, 1, ctx->stream);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    const int lrc = launch_lp_any(p, a, 1);
+    hipError_t e = lrc == MIPX_OK ? hipStreamSynchronize(ctx->stream) : hipSuccess;
     (void)hipFree(zeros);
     (void)hipFree(dv);
+    if (lrc != MIPX_OK) return lrc;
     if (e != hipSuccess) return fail(ctx, MIPX_EHIP, "mipx_problem_set_anchor", e);
     p->anchor_on = true;
     return MIPX_OK;

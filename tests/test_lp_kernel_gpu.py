@@ -202,10 +202,13 @@ def test_c2_batch_of_1024_independent_roots(gpu_ctx, oracle):
         assert abs(g['obj'][k] - c[k] @ g['x'][k]) <= 1e-9 * max(1, abs(g['obj'][k]))
 
 
-def test_anchored_refactorisation(gpu_ctx, oracle):
+@pytest.mark.parametrize('n,m,kernel', [(256, 128, 'lp_dual_simplex<7,19,4>'), (300, 200, 'lp_dual_simplex_big')])
+def test_anchored_refactorisation(n, m, kernel, gpu_ctx, oracle):
     """Warm starts that refactor from the root's tableau instead of the slack basis: bit-exact
-    against the oracle doing the same, far fewer pivots, same optima within rounding."""
-    A, b, c, l, u, _ = random_dense_milp_arrays(256, 128, seed=0)
+    against the oracle doing the same, far fewer pivots, same optima within rounding (register
+    kernel and the HBM-streaming one)."""
+    A, b, c, l, u, _ = random_dense_milp_arrays(n, m, seed=0)
+    assert _ffi.kernel_name(m, n) == kernel
     p = _ffi.Problem(gpu_ctx, A, b, c)
     root = p.solve_batch(l[None], u[None])
     L, U, V = _children(A, b, c, l, u, root, 16)
