@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 from simple_mip_solver_amd import _ffi  # noqa: E402
 from simple_mip_solver_amd.generators import random_dense_milp_arrays  # noqa: E402
-from simple_mip_solver_amd.parallel import exchange, global_gap  # noqa: E402
+from simple_mip_solver_amd.parallel import PseudoCostExchange, exchange, global_gap  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 
@@ -96,6 +96,8 @@ def main():
         assert st['status'] == 4, f'tree finished during ramp-up: {st}'
     ramp = dict(st)
     tree.keep_shard(rank, world)
+    pcx = PseudoCostExchange(n)
+    pcx.start(*tree.pseudo_cost_arrays())  # identical on every rank after the replicated ramp-up
 
     def run_steps(k):
         # inside one call the engine overlaps the host half of step i with the GPU half of i+1
@@ -185,6 +187,8 @@ def main():
                                     [st['evaluated_nodes']])
             if gp < st['primal_bound']:
                 tree.set_primal_bound(gp)
+            # pseudo-cost tables: SUM of what every rank added since the last exchange
+            tree.set_pseudo_cost_arrays(*pcx.merge(dist, device, *tree.pseudo_cost_arrays()))
     barrier()
     elapsed = time.perf_counter() - t0
     after = tree.stats()
@@ -231,7 +235,8 @@ def main():
                 'primal_bound': None if gp == float('inf') else gp, 'dual_bound': gd,
                 'gap': gap, 'time_to_optimal': tto,
                 'parallelism': f'open nodes sharded x{world}, per-GPU best-first queue, '
-                               f'allreduce(MIN) incumbent/bound every {args.exchange_every} steps'},
+                               f'allreduce(MIN) incumbent/bound + allreduce(SUM) pseudo-cost updates every '
+                               f'{args.exchange_every} steps'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'launch_ms': launch_s * 1e3,

@@ -219,6 +219,10 @@ int mipx_tree_set_primal_bound(mipx_tree *t, double bound); /* initial_primal_bo
 int mipx_tree_set_anchor_mode(mipx_tree *t, int on);
 int mipx_tree_pseudo_costs(mipx_tree *t, double *cost_l, double *cost_r, int32_t *times_l,
                            int32_t *times_r);
+/* Install a pseudo-cost table (n entries each): the merged table of a multi-GPU exchange
+ * (PseudoCostBranchNode.pseudo_costs shared through _kwargs, branch/pseudo_cost.py:38-43). */
+int mipx_tree_set_pseudo_costs(mipx_tree *t, const double *cost_l, const double *cost_r,
+                               const int32_t *times_l, const int32_t *times_r);
 /* Copy the records of up to max_nodes open nodes (queue-array order) to HOST buffers without
  * removing them: l, u (max_nodes x n), vstat (max_nodes x (n+m)), dual_bound (max_nodes); any may
  * be NULL.  Returns the number copied (used by bench.py to time the CPU oracle on the very LPs the

@@ -23,7 +23,7 @@ SYMBOLS = [
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
     'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
-    'mipx_tree_solution', 'mipx_tree_set_primal_bound', 'mipx_tree_pseudo_costs',
+    'mipx_tree_solution', 'mipx_tree_set_primal_bound', 'mipx_tree_pseudo_costs', 'mipx_tree_set_pseudo_costs',
     'mipx_tree_set_trace', 'mipx_tree_trace', 'mipx_tree_peek_open', 'mipx_tree_keep_shard',
 ]
 
@@ -357,6 +357,23 @@ class Tree:
                 out[i] = {'left': {'cost': float(cl[i]), 'times': int(tl[i])},
                           'right': {'cost': float(cr[i]), 'times': int(tr[i])}}
         return out
+
+    def pseudo_cost_arrays(self):
+        """(cost_l, cost_r, times_l, times_r) as arrays over all n variables."""
+        n = self.problem.n
+        cl, cr = np.zeros(n), np.zeros(n)
+        tl, tr = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self.problem.ctx.check(lib().mipx_tree_pseudo_costs(self._h, _ptr(cl), _ptr(cr), _ptr(tl),
+                                                            _ptr(tr)), 'mipx_tree_pseudo_costs')
+        return cl, cr, tl, tr
+
+    def set_pseudo_cost_arrays(self, cl, cr, tl, tr):
+        cl = np.ascontiguousarray(cl, np.float64); cr = np.ascontiguousarray(cr, np.float64)
+        tl = np.ascontiguousarray(tl, np.int32); tr = np.ascontiguousarray(tr, np.int32)
+        L = lib()
+        L.mipx_tree_set_pseudo_costs.argtypes = [_vp, _vp, _vp, _vp, _vp]
+        self.problem.ctx.check(L.mipx_tree_set_pseudo_costs(self._h, _ptr(cl), _ptr(cr), _ptr(tl), _ptr(tr)),
+                               'mipx_tree_set_pseudo_costs')
 
     def peek_open(self, max_nodes):
         """(l, u, vstat, dual_bound) of up to max_nodes open nodes, without removing them."""

@@ -874,6 +874,20 @@ int mipx_tree_pseudo_costs(mipx_tree *t, double *cost_l, double *cost_r, int32_t
     return MIPX_OK;
 }
 
+/* Replace the pseudo-cost table (multi-GPU: the ranks all-reduce their updates -- the table is a
+ * running mean, hence sum-decomposable -- and install the merged table). */
+int mipx_tree_set_pseudo_costs(mipx_tree *t, const double *cost_l, const double *cost_r,
+                               const int32_t *times_l, const int32_t *times_r) {
+    if (!t || !cost_l || !cost_r || !times_l || !times_r) return MIPX_EINVAL;
+    std::memcpy(t->cost_l.data(), cost_l, (size_t)t->n * 8);
+    std::memcpy(t->cost_r.data(), cost_r, (size_t)t->n * 8);
+    std::memcpy(t->times_l.data(), times_l, (size_t)t->n * 4);
+    std::memcpy(t->times_r.data(), times_r, (size_t)t->n * 4);
+    for (int j = 0; j < t->n; j++) t->has_entry[j] = (times_l[j] > 0 || times_r[j] > 0) ? 1 : 0;
+    t->table_dirty = true;
+    return MIPX_OK;
+}
+
 /* Copy the records (bounds + warm-start basis) of up to max_nodes open nodes, in queue-array
  * order, to host buffers without removing them; returns how many were copied. */
 int64_t mipx_tree_peek_open(mipx_tree *t, int64_t max_nodes, double *l, double *u, int8_t *vstat,

@@ -51,3 +51,41 @@ def global_gap(primal_bound, dual_bound):
     if primal_bound == INF:
         return None
     return abs(primal_bound - dual_bound) / abs(primal_bound)
+
+
+class PseudoCostExchange:
+    """Merges the ranks' pseudo-cost tables (collective C3).
+
+    An entry is a running mean of branch-cost samples (branch/pseudo_cost.py:97-98), i.e.
+    sum / count: each rank all-reduces (SUM) what it added since the last exchange --
+    delta(cost * times) as f64 and delta(times) as i64, 32 bytes per variable -- and rebuilds the
+    means from the global sums.  `base` is the table every rank agreed on last time.
+    """
+
+    def __init__(self, n):
+        self.base_sum = np.zeros((2, n))
+        self.base_times = np.zeros((2, n), np.int64)
+
+    def start(self, cost_l, cost_r, times_l, times_r):
+        """The table all ranks share at sharding time (replicated ramp-up): counted once."""
+        times = np.stack([times_l, times_r]).astype(np.int64)
+        self.base_sum = np.stack([cost_l, cost_r]).astype(np.float64) * times
+        self.base_times = times
+
+    def merge(self, dist, device, cost_l, cost_r, times_l, times_r):
+        """Local table in, merged table out (same four arrays); single process: unchanged."""
+        if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+            return cost_l, cost_r, times_l, times_r
+        import torch
+        cost = np.stack([cost_l, cost_r]).astype(np.float64)
+        times = np.stack([times_l, times_r]).astype(np.int64)
+        d_sum = torch.tensor(cost * times - self.base_sum, dtype=torch.float64, device=device)
+        d_times = torch.tensor(times - self.base_times, dtype=torch.int64, device=device)
+        dist.all_reduce(d_sum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(d_times, op=dist.ReduceOp.SUM)
+        self.base_sum = self.base_sum + d_sum.cpu().numpy()
+        self.base_times = self.base_times + d_times.cpu().numpy()
+        mean = np.divide(self.base_sum, self.base_times, out=np.zeros_like(self.base_sum),
+                         where=self.base_times > 0)
+        t32 = self.base_times.astype(np.int32)
+        return mean[0], mean[1], t32[0], t32[1]

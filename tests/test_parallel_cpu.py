@@ -35,6 +35,27 @@ WORKER = textwrap.dedent('''
     # step 3: both hold the same incumbent value: the lowest rank is reported
     out = exchange(dist, 'cpu', -9.0, -9.0, [0, 0])
     assert out == (-9.0, -9.0, [0, 0], 0), out
+    # pseudo-cost tables: a shared start (replicated ramp-up), then each rank adds its own samples
+    import numpy as np
+    from simple_mip_solver_amd.parallel import PseudoCostExchange
+    n = 4
+    px = PseudoCostExchange(n)
+    start = (np.array([2.0, 0, 0, 1.0]), np.array([4.0, 0, 0, 0]), np.array([1, 0, 0, 2], np.int32),
+             np.array([1, 0, 0, 0], np.int32))
+    px.start(*start)
+    cl, cr, tl, tr = [a.copy() for a in start]
+    if rank == 0:   # variable 0 left: one more sample of 4 -> mean 3 over 2; variable 1 left: new, 5
+        cl[0], tl[0] = 3.0, 2
+        cl[1], tl[1] = 5.0, 1
+    else:           # variable 0 left: one more sample of 6 -> mean 4 over 2; variable 3 right: new, 7
+        cl[0], tl[0] = 4.0, 2
+        cr[3], tr[3] = 7.0, 1
+    ml, mr, ntl, ntr = px.merge(dist, 'cpu', cl, cr, tl, tr)
+    assert np.allclose(ml, [4.0, 5.0, 0, 1.0]) and list(ntl) == [3, 1, 0, 2], (ml, ntl)   # (2+4+6)/3
+    assert np.allclose(mr, [4.0, 0, 0, 7.0]) and list(ntr) == [1, 0, 0, 1], (mr, ntr)
+    # a second exchange with no new samples changes nothing
+    ml2, mr2, ntl2, ntr2 = px.merge(dist, 'cpu', ml, mr, ntl, ntr)
+    assert np.array_equal(ml2, ml) and np.array_equal(ntl2, ntl) and np.array_equal(mr2, mr)
     dist.barrier()
     dist.destroy_process_group()
     print('rank', rank, 'ok')
