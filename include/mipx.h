@@ -237,7 +237,7 @@ int mipx_tree_set_trace(mipx_tree *t, int on);
 int64_t mipx_tree_trace(mipx_tree *t, int64_t capacity, int64_t *node_id, int32_t *lp_status,
                         int32_t *branch_var, double *objective);
 
-/* Name of the kernel instantiation that (m, n) dispatches to, e.g. "lp_dual_simplex<7,19,4>". */
+/* Name of the kernel instantiation that (m, n) dispatches to, e.g. "lp_dual_simplex<7,5,16>". */
 int mipx_kernel_name(int m, int n, char *buf, size_t buflen);
 
 #ifdef __cplusplus

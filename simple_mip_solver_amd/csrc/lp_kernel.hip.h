@@ -4,10 +4,13 @@
 // (simple_mip_solver/nodes/base_node.py:273, :645-646).  Not a translation of anything: the
 // reference has no kernel.  Design:
 //
-//   * The condensed simplex tableau T (m x n, f64) lives in VGPRs for the whole solve: lane l of
-//     tableau wave w owns T[w + NW*ii][l + 64*jj], ii < R, jj < C -- whole rows belong to one wave, a
-//     column to one lane position of every wave.  256x128 -> 7 waves x 64 lanes x 19x4 doubles of
-//     registers on one CU; it never touches HBM again after the initial coalesced read.
+//   * The condensed simplex tableau T (m x n, f64) lives in VGPRs for the whole solve.  A tableau
+//     wave is 4 row groups x 16 column lanes: lane (rg, cl) of wave w owns rows g + NG*ii of its
+//     group g = 4w + rg and the adjacent column pairs 32*pp + 2*cl + {0,1}.  256x128 -> 7 waves x
+//     64 lanes x 5x16 doubles of registers on one CU; it never touches HBM again after the initial
+//     read.  A row then sits in 16 lanes x 16 registers of one wave and a column in 4 lanes x 5
+//     registers of every wave: moving either through LDS takes few store instructions (an LDS
+//     store costs the CU-wide pipe the same whatever its exec mask).
 //   * Wave 0 is the control wave: it holds no tableau rows but both borders in registers (reduced
 //     costs and nonbasic variable/side per column; beta0, basic values a + b*M, basic variable and
 //     its bounds per row) and runs every selection -- leaving row, Harris ratio test, the
@@ -299,10 +302,9 @@ struct alignas(16) MailB {  // control wave -> tableau waves: the pivot column
 
 template <int NW, int R, int C, int MP>
 struct Smem {
-    static constexpr int NP = 64 * C;
-    double row[NP];     // pivot row T[r][.]
-    static constexpr int RS = (R + 2) & ~1;  // row stride of alpha: even, so parts stay 16-byte aligned
-    alignas(16) double alpha[NW * RS];  // pivot column, tableau wave w's rows at [w*RS ..)
+    static constexpr int NP = 16 * C;
+    alignas(16) double row[NP];  // pivot row T[r][.]
+    double alpha[4 * NW * R];    // pivot column T[.][q]
     double lo[NP];      // structural bounds by variable index
     double up[NP];
     double va[NP];      // nonbasic values a + b*M by column
@@ -310,8 +312,8 @@ struct Smem {
     double d[NP];       // staging of the borders at setup / output (they live in the control wave's
     double key[NP];     //   registers in between); key: x assembly
     double beta0[MP];
-    double ba[NW * R];
-    double bb[NW * R];
+    double ba[4 * NW * R];
+    double bb[4 * NW * R];
     MailA mbA;
     MailB mbB;
     int bvar[MP];
@@ -329,8 +331,6 @@ struct Smem {
     unsigned long long prof[16];
 #endif
 };
-// position of row i in Smem::alpha
-#define MIPX_AIDX(i_) (((i_) % NW) * RS + (i_) / NW)
 // wave-uniform reads of the mailboxes: one ds_read_b128 each, fields moved to scalar registers
 __device__ __forceinline__ void read_mail(const MailA &mb, int &win, int &lvmeta, double &x) {
     const int4 v = *reinterpret_cast<const int4 *>(&mb);
@@ -354,15 +354,18 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
         dst_ = arr_[0];                                                                     \
         _Pragma("unroll") for (int t_ = 1; t_ < n_; t_++) dst_ = (k_) == t_ ? arr_[t_] : dst_; \
     } while (0)
-// tableau wave: the lane that holds column q stores the wave's part of it in s.alpha, for the
-// control wave and for the wave itself: every lane reads it back (broadcast reads; a v_readlane
-// per value would cost ~10 cycles each), after one count on s.seq
+// row / column of a tableau lane's element (ii, jj)
+#define MIPX_ROW(ii_) (grp + NG * (ii_))
+#define MIPX_COL(jj_) (32 * ((jj_) >> 1) + 2 * cl + ((jj_)&1))
+// tableau wave: the four lanes that hold column q (one per row group) store the wave's part of it
+// in s.alpha, for the control wave and for the wave itself: every lane reads its rows back
+// (a v_readlane per value would cost ~10 cycles each), after one count on s.seq
 #define MIPX_PUBLISH_COL(q_)                                                                \
     do {                                                                                    \
-        const int ql_ = (q_) >> 6;                                                          \
-        if (lane == ((q_)&63)) {                                                            \
-            _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == ql_) {               \
-                _Pragma("unroll") for (int ii = 0; ii < R; ii++) s.alpha[tw * RS + ii] = T[ii][jj]; \
+        const int qjj_ = 2 * ((q_) >> 5) + ((q_)&1);                                        \
+        if (cl == (((q_)&31) >> 1)) {                                                       \
+            _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == qjj_) {              \
+                _Pragma("unroll") for (int ii = 0; ii < R; ii++) s.alpha[MIPX_ROW(ii)] = T[ii][jj]; \
             }                                                                               \
         }                                                                                   \
         /* the count first: the control wave is waiting for it.  (The release orders the stores */ \
@@ -371,7 +374,7 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                              \
         __builtin_amdgcn_wave_barrier();                                                    \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                              \
-        _Pragma("unroll") for (int ii = 0; ii < R; ii++) al[ii] = s.alpha[tw * RS + ii];    \
+        _Pragma("unroll") for (int ii = 0; ii < R; ii++) al[ii] = s.alpha[MIPX_ROW(ii)];    \
     } while (0)
 // the control wave waits until all NW parts of the current pivot column are in s.alpha
 #define MIPX_AWAIT_COL(target_)                                                             \
@@ -379,36 +382,38 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
         while (__hip_atomic_load(&s.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (target_)) \
             __builtin_amdgcn_s_sleep(1);                                                    \
     } while (0)
-// T[r][.] -> s.row (by the tableau wave that holds row r)
+// T[r][.] -> s.row (by the 16 lanes of the row group that holds row r)
 #define MIPX_EXTRACT_ROW(r_)                                                                \
     do {                                                                                    \
-        const int rl_ = (r_) / NW;                                                          \
-        _Pragma("unroll") for (int ii = 0; ii < R; ii++) if (ii == rl_) {                   \
-            _Pragma("unroll") for (int jj = 0; jj < C; jj++) s.row[lane + 64 * jj] = T[ii][jj]; \
+        const int rl_ = (r_) / NG;                                                          \
+        if (grp == (r_) % NG) {                                                             \
+            _Pragma("unroll") for (int ii = 0; ii < R; ii++) if (ii == rl_) {               \
+                _Pragma("unroll") for (int jj = 0; jj < C; jj++) s.row[MIPX_COL(jj)] = T[ii][jj]; \
+            }                                                                               \
         }                                                                                   \
     } while (0)
-// rank-1 update of the register tableau for the pivot on (r, q): this wave's part of column q
+// rank-1 update of the register tableau for the pivot on (r, q): this lane's part of column q
 // is in al[] (MIPX_PUBLISH_COL), row r in s.row.  Row r and column q come out of the fma sweep as
 // junk and are overwritten right after it.
 #define MIPX_UPDATE_T(r_, q_, pinv_)                                                        \
     do {                                                                                    \
-        const int rw_ = (r_) % NW, rl_ = (r_) / NW;                                         \
-        const int qlane_ = (q_)&63, ql_ = (q_) >> 6;                                        \
+        const int rg_ = (r_) % NG, rl_ = (r_) / NG;                                         \
+        const int qcl_ = ((q_)&31) >> 1, qjj_ = 2 * ((q_) >> 5) + ((q_)&1);                 \
         double rh[C];                                                                       \
-        _Pragma("unroll") for (int jj = 0; jj < C; jj++) rh[jj] = s.row[lane + 64 * jj] * (pinv_); \
+        _Pragma("unroll") for (int jj = 0; jj < C; jj++) rh[jj] = s.row[MIPX_COL(jj)] * (pinv_); \
         _Pragma("unroll") for (int ii = 0; ii < R; ii++) {                                  \
             _Pragma("unroll") for (int jj = 0; jj < C; jj++)                                \
                 T[ii][jj] = fma(-al[ii], rh[jj], T[ii][jj]);                                \
         }                                                                                   \
-        if (lane == qlane_) { /* column q <- -alpha * (1/p) */                              \
-            _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == ql_) {               \
+        if (cl == qcl_) { /* column q <- -alpha * (1/p) */                                  \
+            _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == qjj_) {              \
                 _Pragma("unroll") for (int ii = 0; ii < R; ii++) T[ii][jj] = -al[ii] * (pinv_); \
             }                                                                               \
         }                                                                                   \
-        if (tw == rw_) { /* row r <- row * (1/p), and 1/p at the pivot position */          \
+        if (grp == rg_) { /* row r <- row * (1/p), and 1/p at the pivot position */         \
             _Pragma("unroll") for (int ii = 0; ii < R; ii++) if (ii == rl_) {               \
                 _Pragma("unroll") for (int jj = 0; jj < C; jj++)                            \
-                    T[ii][jj] = (lane == qlane_ && jj == ql_) ? (pinv_) : rh[jj];           \
+                    T[ii][jj] = (cl == qcl_ && jj == qjj_) ? (pinv_) : rh[jj];              \
             }                                                                               \
         }                                                                                   \
     } while (0)
@@ -416,9 +421,9 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
 #define MIPX_UPDATE_COLS(q_, pinv_, lvmeta_)                                                \
     do {                                                                                    \
         double dq_;                                                                         \
-        MIPX_PICK(dq_, cD, C, (q_) >> 6);                                                   \
+        MIPX_PICK(dq_, cD, PJ, (q_) >> 6);                                                  \
         dq_ = readlane_f64(dq_, (q_)&63);                                                   \
-        _Pragma("unroll") for (int kk = 0; kk < C; kk++) {                                  \
+        _Pragma("unroll") for (int kk = 0; kk < PJ; kk++) {                                 \
             const int j = lane + 64 * kk;                                                   \
             const double rho_ = s.row[j] * (pinv_);                                         \
             const double upd_ = fma(-dq_, rho_, cD[kk]);                                    \
@@ -532,11 +537,12 @@ _Pragma("unroll")                                                               
 template <int NW, int R, int C, int MP>
 __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
     constexpr int NT = 64 * (NW + 1);
-    constexpr int NP = 64 * C;
-    static_assert((NP & (NP - 1)) == 0, "padded column count must be a power of two");
-    static_assert(MP <= NW * R, "the tableau waves must cover every row");
+    constexpr int NG = 4 * NW;          // row groups of the workgroup (4 per tableau wave)
+    constexpr int NP = 16 * C;          // padded columns: 16 column lanes x C columns each
+    static_assert((NP & (NP - 1)) == 0 && NP % 64 == 0 && C % 2 == 0, "power-of-two columns in adjacent pairs");
+    static_assert(MP <= NG * R, "the tableau waves must cover every row");
     constexpr int PI = (MP + 63) / 64;  // rows per lane of the control wave
-    constexpr int RS = (R + 2) & ~1;    // row stride of s.alpha
+    constexpr int PJ = NP / 64;         // columns per lane of the control wave
     __shared__ Smem<NW, R, C, MP> s;
 
     const int tid = threadIdx.x;
@@ -544,6 +550,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool ctl = wave == 0;
     const int tw = wave - 1;  // tableau wave index
+    const int cl = lane & 15;                 // tableau lanes: column lane,
+    const int grp = 4 * tw + (lane >> 4);     //   row group (rows grp + NG*ii)
     const int m = g.m, n = g.n;
     const int nv = n + m;
     const double INF = __builtin_huge_val();
@@ -556,14 +564,13 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
     if (tid < 16) s.prof[tid] = 0;
     unsigned long long tprev = clock64();
 #endif
-    double T[R][C];  // tableau waves: T[ii][jj] = tableau[tw + NW*ii][lane + 64*jj]
+    double T[R][C];  // tableau waves: T[ii][jj] = tableau[grp + NG*ii][32*(jj/2) + 2*cl + jj%2]
     double al[R];    // tableau waves: their part of the current pivot column
     // control wave: column border (column j = lane + 64*kk) and row border (row i = lane + 64*kk)
-    double cD[C];    // reduced cost
-    int cM[C];       // nonbasic variable << 3 | fixed << 2 | side
+    double cD[PJ];   // reduced cost
+    int cM[PJ];      // nonbasic variable << 3 | fixed << 2 | side
     double rB0[PI], rBa[PI], rBb[PI], rLo[PI], rUp[PI];
     int rM[PI];      // basic variable << 2 | pivoted by the refactorisation << 1 | wanted basic
-    int aix[PI];     // position of row i in s.alpha
     const size_t src = g.slot ? (size_t)g.slot[node] : (size_t)node;
     const double *gA = g.A + (size_t)node * g.A_stride;
     const double *gb = g.b + (size_t)node * g.b_stride;
@@ -586,14 +593,27 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
         // for HBM.  Every load is issued unconditionally from a clamped address (512 contiguous
         // bytes per wave instruction); sign and padding are fixed where the values are first used
         const double *tsrc = anchored ? g.anchor_T : gA;
-        int joff[C];
+        if ((n & 1) == 0 && n >= 2) {  // adjacent column pairs as one 16-byte load
+            int poff[C / 2];
 #pragma unroll
-        for (int jj = 0; jj < C; jj++) joff[jj] = min(lane + 64 * jj, n - 1);
+            for (int pp = 0; pp < C / 2; pp++) poff[pp] = min(32 * pp + 2 * cl, n - 2);
 #pragma unroll
-        for (int ii = 0; ii < R; ii++) {
-            const double *arow = tsrc + (size_t)min(tw + NW * ii, m > 0 ? m - 1 : 0) * n;
+            for (int ii = 0; ii < R; ii++) {
+                const double *arow = tsrc + (size_t)min(MIPX_ROW(ii), m > 0 ? m - 1 : 0) * n;
 #pragma unroll
-            for (int jj = 0; jj < C; jj++) T[ii][jj] = m > 0 ? arow[joff[jj]] : 0.0;
+                for (int pp = 0; pp < C / 2; pp++) {
+                    const double2 v = m > 0 ? *reinterpret_cast<const double2 *>(arow + poff[pp]) : double2{0.0, 0.0};
+                    T[ii][2 * pp] = v.x;
+                    T[ii][2 * pp + 1] = v.y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < R; ii++) {
+                const double *arow = tsrc + (size_t)min(MIPX_ROW(ii), m > 0 ? m - 1 : 0) * n;
+#pragma unroll
+                for (int jj = 0; jj < C; jj++) T[ii][jj] = m > 0 ? arow[min(MIPX_COL(jj), n - 1)] : 0.0;
+            }
         }
     }
     {
@@ -651,7 +671,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
     }
     // the control wave takes the borders into registers
 #pragma unroll
-    for (int kk = 0; kk < C; kk++) {
+    for (int kk = 0; kk < PJ; kk++) {
         cD[kk] = s.d[lane + 64 * kk];
         cM[kk] = s.meta[lane + 64 * kk];
     }
@@ -667,7 +687,6 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
         rLo[kk] = st ? s.lo[st ? v : 0] : 0.0;
         rUp[kk] = st ? s.up[st ? v : 0] : INF;
         rM[kk] = (v << 2) | ((v >= 0 && s.wantb[v < 0 ? 0 : v]) ? 1 : 0);
-        aix[kk] = MIPX_AIDX(ic);
     }
     KPROF_SETUP_MARK(13);
     __syncthreads();
@@ -677,7 +696,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
         for (int ii = 0; ii < R; ii++) {
 #pragma unroll
             for (int jj = 0; jj < C; jj++)
-                T[ii][jj] = (tw + NW * ii < m && lane + 64 * jj < n) ? sgn * T[ii][jj] : 0.0;
+                T[ii][jj] = (MIPX_ROW(ii) < m && MIPX_COL(jj) < n) ? sgn * T[ii][jj] : 0.0;
         }
     }
 
@@ -703,7 +722,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
 #pragma unroll
                 for (int kk = 0; kk < PI; kk++) {
                     const int i = lane + 64 * kk;
-                    av[kk] = i < MP ? s.alpha[aix[kk]] : 0.0;
+                    av[kk] = i < MP ? s.alpha[i < MP ? i : 0] : 0.0;
                     const double a = fabs(av[kk]);
                     const bool ok = i < m && a > kPivTol;
                     const bool wanted = rM[kk] & 1, ent = rM[kk] & 2;
@@ -735,7 +754,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
                     }
                     // beta0 and the basis list, right away
                     int cmq;
-                    MIPX_PICK(cmq, cM, C, q >> 6);
+                    MIPX_PICK(cmq, cM, PJ, q >> 6);
                     const int ev = __builtin_amdgcn_readlane(cmq, q & 63) >> 3;
                     const double rhon = readlane_f64(b0r, rr & 63) * pinv;
                     const double elo = ev < n ? s.lo[ev < n ? ev : 0] : 0.0;
@@ -769,7 +788,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
                 int r, lvmeta;
                 double pinv;
                 read_mail(s.mbA, r, lvmeta, pinv);
-                if (r >= 0 && tw == r % NW) MIPX_EXTRACT_ROW(r);
+                if (r >= 0) MIPX_EXTRACT_ROW(r);
                 __syncthreads();  // B
                 KPROF_MARK(10);
                 if (r >= 0) MIPX_UPDATE_T(r, q, pinv);
@@ -786,7 +805,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
         int nfake = 0;  // nonbasic columns at the symbolic bound M (control wave)
         if (ctl) {
 #pragma unroll
-            for (int kk = 0; kk < C; kk++) {
+            for (int kk = 0; kk < PJ; kk++) {
                 const int j = lane + 64 * kk;
                 int side = 0;
                 if (j < n) {
@@ -809,49 +828,75 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
         __syncthreads();
         if (!ctl) {
             const int nf0 = __builtin_amdgcn_readfirstlane(s.nfake0);
-            constexpr int RP = R <= 16 ? 16 : 32;
-            double va[C], vb[C];
+            // row sums over the padded columns with the canonical fold-in-half tree: column
+            // j = 32*pp + 2*cl + e, so the levels are pp (in the thread, per e), then the column
+            // lanes cl + 8, 4, 2, 1 (DPP inside the 16-lane row group), then e last
+            double va[C];
 #pragma unroll
-            for (int jj = 0; jj < C; jj++) {
-                va[jj] = s.va[lane + 64 * jj];
-                vb[jj] = s.vb[lane + 64 * jj];
-            }
-            double pr[RP];
+            for (int jj = 0; jj < C; jj++) va[jj] = s.va[MIPX_COL(jj)];
+            double s0[R], s1[R];
 #pragma unroll
-            for (int ii = 0; ii < RP; ii++) {
+            for (int ii = 0; ii < R; ii++) {
                 double t[C];
 #pragma unroll
-                for (int jj = 0; jj < C; jj++) t[jj] = ii < R ? T[ii < R ? ii : 0][jj] * va[jj] : 0.0;
+                for (int jj = 0; jj < C; jj++) t[jj] = T[ii][jj] * va[jj];
 #pragma unroll
-                for (int h = C / 2; h >= 1; h >>= 1) {
+                for (int h = C / 4; h >= 1; h >>= 1) {  // pairs pp and pp + h, both columns of the pair
 #pragma unroll
-                    for (int jj = 0; jj < h; jj++) t[jj] = t[jj] + t[jj + h];
+                    for (int k = 0; k < 2 * h; k++) t[k] = t[k] + t[k + 2 * h];
                 }
-                pr[ii] = t[0];
+                s0[ii] = t[0];
+                s1[ii] = t[1];
             }
-            MIPX_ROWSUMS(pr, RP);
-            const double sa = pr[0];
-            double sb = 0.0;
+#pragma unroll
+            for (int ii = 0; ii < R; ii++) {
+                s0[ii] = s0[ii] + dpp_f64<0x108, 0xf>(s0[ii]);  // row_shl:8
+                s1[ii] = s1[ii] + dpp_f64<0x108, 0xf>(s1[ii]);
+                s0[ii] = s0[ii] + dpp_f64<0x104, 0xf>(s0[ii]);  // row_shl:4
+                s1[ii] = s1[ii] + dpp_f64<0x104, 0xf>(s1[ii]);
+                s0[ii] = s0[ii] + dpp_f64<0x102, 0xf>(s0[ii]);  // row_shl:2
+                s1[ii] = s1[ii] + dpp_f64<0x102, 0xf>(s1[ii]);
+                s0[ii] = s0[ii] + dpp_f64<0x101, 0xf>(s0[ii]);  // row_shl:1
+                s1[ii] = s1[ii] + dpp_f64<0x101, 0xf>(s1[ii]);
+            }
+            if (cl == 0) {
+#pragma unroll
+                for (int ii = 0; ii < R; ii++) {
+                    s.ba[MIPX_ROW(ii)] = s0[ii] + s1[ii];
+                    s.bb[MIPX_ROW(ii)] = 0.0;
+                }
+            }
             if (nf0 != 0) {  // the M parts: all zero unless some nonbasic sits at the symbolic bound
 #pragma unroll
-                for (int ii = 0; ii < RP; ii++) {
+                for (int jj = 0; jj < C; jj++) va[jj] = s.vb[MIPX_COL(jj)];
+#pragma unroll
+                for (int ii = 0; ii < R; ii++) {
                     double t[C];
 #pragma unroll
-                    for (int jj = 0; jj < C; jj++) t[jj] = ii < R ? T[ii < R ? ii : 0][jj] * vb[jj] : 0.0;
+                    for (int jj = 0; jj < C; jj++) t[jj] = T[ii][jj] * va[jj];
 #pragma unroll
-                    for (int h = C / 2; h >= 1; h >>= 1) {
+                    for (int h = C / 4; h >= 1; h >>= 1) {
 #pragma unroll
-                        for (int jj = 0; jj < h; jj++) t[jj] = t[jj] + t[jj + h];
+                        for (int k = 0; k < 2 * h; k++) t[k] = t[k] + t[k + 2 * h];
                     }
-                    pr[ii] = t[0];
+                    s0[ii] = t[0];
+                    s1[ii] = t[1];
                 }
-                MIPX_ROWSUMS(pr, RP);
-                sb = pr[0];
-            }
-            const int ii = rowsum_row(lane, RP);
-            if ((lane & (RP == 32 ? 1 : 3)) == 0 && ii < R) {
-                s.ba[tw + NW * ii] = sa;
-                s.bb[tw + NW * ii] = 0.0 - sb;
+#pragma unroll
+                for (int ii = 0; ii < R; ii++) {
+                    s0[ii] = s0[ii] + dpp_f64<0x108, 0xf>(s0[ii]);
+                    s1[ii] = s1[ii] + dpp_f64<0x108, 0xf>(s1[ii]);
+                    s0[ii] = s0[ii] + dpp_f64<0x104, 0xf>(s0[ii]);
+                    s1[ii] = s1[ii] + dpp_f64<0x104, 0xf>(s1[ii]);
+                    s0[ii] = s0[ii] + dpp_f64<0x102, 0xf>(s0[ii]);
+                    s1[ii] = s1[ii] + dpp_f64<0x102, 0xf>(s1[ii]);
+                    s0[ii] = s0[ii] + dpp_f64<0x101, 0xf>(s0[ii]);
+                    s1[ii] = s1[ii] + dpp_f64<0x101, 0xf>(s1[ii]);
+                }
+                if (cl == 0) {
+#pragma unroll
+                    for (int ii = 0; ii < R; ii++) s.bb[MIPX_ROW(ii)] = 0.0 - (s0[ii] + s1[ii]);
+                }
             }
         }
         __syncthreads();
@@ -887,13 +932,13 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
                 KPROF_MARK(1);
                 __syncthreads();  // B: row r is in s.row
                 // (c) Harris ratio test on row r
-                double aa[C], dje[C];
-                bool el[C];
+                double aa[PJ], dje[PJ];
+                bool el[PJ];
                 double k1 = INF;
                 int p1 = kNoCand;
                 const double tol = bland ? 0.0 : kDTol;  // Bland: the textbook ratio dj / |a|
 #pragma unroll
-                for (int kk = 0; kk < C; kk++) {
+                for (int kk = 0; kk < PJ; kk++) {
                     const int j = lane + 64 * kk;
                     const double rv = s.row[j];
                     const double a = __hiloint2double(__double2hiint(rv) ^ sflip, __double2loint(rv));
@@ -914,7 +959,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
                     double k2 = -1.0;
                     int p2 = kNoCand;
 #pragma unroll
-                    for (int kk = 0; kk < C; kk++) {
+                    for (int kk = 0; kk < PJ; kk++) {
                         const int j = lane + 64 * kk;
                         const bool ok = el[kk] & ((j == jmin) | !(dje[kk] > thmax * aa[kk]));
                         keep_max(k2, p2, aa[kk], ((cM[kk] >> 3) << 16) | j, ok);
@@ -928,8 +973,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
                     const int ql = qq & 63, qk = qq >> 6;
                     double t0;
                     int tm;
-                    MIPX_PICK(t0, dje, C, qk);
-                    MIPX_PICK(tm, cM, C, qk);
+                    MIPX_PICK(t0, dje, PJ, qk);
+                    MIPX_PICK(tm, cM, PJ, qk);
                     const double djq = readlane_f64(t0, ql);
                     const int cm = __builtin_amdgcn_readlane(tm, ql);
                     degen = djq <= kDTol ? degen + 1 : 0;
@@ -969,7 +1014,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
 #pragma unroll
                     for (int kk = 0; kk < PI; kk++) {
                         const int i = lane + 64 * kk;
-                        const double a = i < MP ? s.alpha[aix[kk]] : 0.0;
+                        const double a = i < MP ? s.alpha[i < MP ? i : 0] : 0.0;
                         const bool pr = i == r;
                         const double u0 = fma(-a, rhon, rB0[kk]), u1 = fma(-a, ta, rBa[kk]), u2 = fma(-a, tb, rBb[kk]);
                         rB0[kk] = pr ? rhon : u0;
@@ -994,7 +1039,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
                 read_mail(s.mbA, win, lvmeta, la);
                 if (win >> 16) break;
                 const int r = win & 0x7fff;
-                if (tw == r % NW) MIPX_EXTRACT_ROW(r);  // (b)
+                MIPX_EXTRACT_ROW(r);  // (b)
                 KPROF_MARK(1);
                 __syncthreads();  // B
                 __syncthreads();  // C
@@ -1030,7 +1075,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
 #endif
     if (ctl) {
 #pragma unroll
-        for (int kk = 0; kk < C; kk++) {
+        for (int kk = 0; kk < PJ; kk++) {
             const int j = lane + 64 * kk;
             s.d[j] = cD[kk];
             s.nvar[j] = cM[kk] >> 3;
@@ -1081,7 +1126,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
         for (int ii = 0; ii < R; ii++) {
 #pragma unroll
             for (int jj = 0; jj < C; jj++) {
-                const int i = tw + NW * ii, j = lane + 64 * jj;
+                const int i = MIPX_ROW(ii), j = MIPX_COL(jj);
                 if (!ctl && i < m && j < n) dT[(size_t)i * n + j] = T[ii][jj];
             }
         }
@@ -1132,7 +1177,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
 #undef MIPX_PICK
 #undef MIPX_ROWSUMS
 #undef MIPX_ROWSUM_STEP
-#undef MIPX_AIDX
+#undef MIPX_ROW
+#undef MIPX_COL
 #undef MIPX_LEAVE_SELECT
 
 }  // namespace mipx

@@ -72,12 +72,12 @@ void launch_cfg(const mipx::LpArgs &a, int grid, hipStream_t st) {
 
 // ordered by on-chip footprint; the first that fits (m <= mp, n <= np) is used
 const KernelCfg kCfgs[] = {
-    // <tableau waves, rows per thread, columns per thread> (+ one control wave):
-    // rows <= waves * R, columns <= 64 * C
-    {32, 64, 128, "lp_dual_simplex<1,32,1>", launch_cfg<1, 32, 1, 32>},
-    {64, 128, 256, "lp_dual_simplex<3,22,2>", launch_cfg<3, 22, 2, 64>},
-    {128, 256, 512, "lp_dual_simplex<7,19,4>", launch_cfg<7, 19, 4, 128>},
-    {192, 256, 512, "lp_dual_simplex<7,28,4>", launch_cfg<7, 28, 4, 192>},
+    // <tableau waves, rows per thread, columns per thread> (+ one control wave); a tableau wave
+    // is 4 row groups x 16 column lanes: rows <= 4 * waves * R, columns <= 16 * C
+    {32, 64, 128, "lp_dual_simplex<1,8,4>", launch_cfg<1, 8, 4, 32>},
+    {64, 128, 256, "lp_dual_simplex<3,6,8>", launch_cfg<3, 6, 8, 64>},
+    {128, 256, 512, "lp_dual_simplex<7,5,16>", launch_cfg<7, 5, 16, 128>},
+    {192, 256, 512, "lp_dual_simplex<7,7,16>", launch_cfg<7, 7, 16, 192>},
 };
 
 const KernelCfg *pick_cfg(int m, int n) {

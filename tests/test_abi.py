@@ -28,9 +28,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_kernel_dispatch_table():
-    assert _ffi.kernel_name(32, 64) == 'lp_dual_simplex<1,32,1>'
-    assert _ffi.kernel_name(128, 256) == 'lp_dual_simplex<7,19,4>'
-    assert _ffi.kernel_name(129, 256) == 'lp_dual_simplex<7,28,4>'
+    assert _ffi.kernel_name(32, 64) == 'lp_dual_simplex<1,8,4>'
+    assert _ffi.kernel_name(128, 256) == 'lp_dual_simplex<7,5,16>'
+    assert _ffi.kernel_name(129, 256) == 'lp_dual_simplex<7,7,16>'
     assert _ffi.kernel_name(512, 1024) == 'lp_dual_simplex_big'   # streamed from HBM
     with pytest.raises(_ffi.MipxError, match='MIPX_ETOOBIG'):
         _ffi.kernel_name(512, 2048)

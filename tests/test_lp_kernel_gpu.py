@@ -114,9 +114,9 @@ def test_s3_root_children_and_probes(gpu_ctx, oracle):
 
 
 def test_with_extra_rows_uses_tall_kernel(gpu_ctx, oracle):
-    # m > 128 (cut rows appended) dispatches to the R=28 instantiation
+    # m > 128 (cut rows appended) dispatches to the tall instantiation
     A, b, c, l, u, _ = random_dense_milp_arrays(200, 150, seed=3)
-    assert '28' in _ffi.kernel_name(150, 200)
+    assert _ffi.kernel_name(150, 200) == 'lp_dual_simplex<7,7,16>'
     p = _ffi.Problem(gpu_ctx, A, b, c)
     g = p.solve_batch(l[None], u[None])
     o = oracle.lp_solve_batch(A, b, c, l[None], u[None])
@@ -202,7 +202,7 @@ def test_c2_batch_of_1024_independent_roots(gpu_ctx, oracle):
         assert abs(g['obj'][k] - c[k] @ g['x'][k]) <= 1e-9 * max(1, abs(g['obj'][k]))
 
 
-@pytest.mark.parametrize('n,m,kernel', [(256, 128, 'lp_dual_simplex<7,19,4>'), (300, 200, 'lp_dual_simplex_big')])
+@pytest.mark.parametrize('n,m,kernel', [(256, 128, 'lp_dual_simplex<7,5,16>'), (300, 200, 'lp_dual_simplex_big')])
 def test_anchored_refactorisation(n, m, kernel, gpu_ctx, oracle):
     """Warm starts that refactor from the root's tableau instead of the slack basis: bit-exact
     against the oracle doing the same, far fewer pivots, same optima within rounding (register
