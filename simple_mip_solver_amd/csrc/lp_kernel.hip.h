@@ -417,6 +417,33 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
             }                                                                               \
         }                                                                                   \
     } while (0)
+// Refactorisation: the next pivot column qn is known in advance, so its values AFTER the pivot on
+// (r, q) are worked out first (same expressions as the sweep will use: fma(-al, rh, T), rh in row r)
+// and handed to the control wave at once; its choice of the next pivot row then overlaps the
+// sweep.  T is not touched here.
+#define MIPX_PUBLISH_NEXT_COL(r_, pinv_, qn_)                                               \
+    do {                                                                                    \
+        const int rg_ = (r_) % NG, rl_ = (r_) / NG;                                         \
+        const int qnjj_ = 2 * ((qn_) >> 5) + ((qn_)&1);                                     \
+        const double rhn_ = s.row[qn_] * (pinv_);                                           \
+        if (cl == (((qn_)&31) >> 1)) {                                                      \
+            _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == qnjj_) {             \
+                _Pragma("unroll") for (int ii = 0; ii < R; ii++) {                          \
+                    const double v_ = fma(-al[ii], rhn_, T[ii][jj]);                        \
+                    s.alpha[MIPX_ROW(ii)] = (grp == rg_ && ii == rl_) ? rhn_ : v_;          \
+                }                                                                           \
+            }                                                                               \
+        }                                                                                   \
+        if (lane == 0) __hip_atomic_fetch_add(&s.seq, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    } while (0)
+// ... and after the sweep every lane picks its rows of that column up for the next pivot
+#define MIPX_READ_COL()                                                                     \
+    do {                                                                                    \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                              \
+        __builtin_amdgcn_wave_barrier();                                                    \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                              \
+        _Pragma("unroll") for (int ii = 0; ii < R; ii++) al[ii] = s.alpha[MIPX_ROW(ii)];    \
+    } while (0)
 // control wave: d after the pivot on (r, q), and the variable that takes over column q
 #define MIPX_UPDATE_COLS(q_, pinv_, lvmeta_)                                                \
     do {                                                                                    \
@@ -791,11 +818,15 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
                 if (r >= 0) MIPX_EXTRACT_ROW(r);
                 __syncthreads();  // B
                 KPROF_MARK(10);
-                if (r >= 0) MIPX_UPDATE_T(r, q, pinv);
-                KPROF_MARK(13);
-                if (w + 1 < nw)  // next column, from registers already updated
-                    MIPX_PUBLISH_COL(__builtin_amdgcn_readfirstlane(s.wlist[w + 1 < nw ? w + 1 : 0]));
+                const int qn = w + 1 < nw ? __builtin_amdgcn_readfirstlane(s.wlist[w + 1 < nw ? w + 1 : 0]) : -1;
+                if (r >= 0 && qn >= 0) MIPX_PUBLISH_NEXT_COL(r, pinv, qn);  // out before the sweep
                 KPROF_MARK(14);
+                if (r >= 0) MIPX_UPDATE_T(r, q, pinv);
+                if (qn >= 0) {
+                    if (r >= 0) MIPX_READ_COL();
+                    else MIPX_PUBLISH_COL(qn);  // (singular column: nothing changed, plain publish)
+                }
+                KPROF_MARK(13);
             }
         }
     }
@@ -1170,6 +1201,8 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
 }
 
 #undef MIPX_PUBLISH_COL
+#undef MIPX_PUBLISH_NEXT_COL
+#undef MIPX_READ_COL
 #undef MIPX_AWAIT_COL
 #undef MIPX_EXTRACT_ROW
 #undef MIPX_UPDATE_T
