@@ -237,3 +237,64 @@ def test_anchored_refactorisation(n, m, kernel, gpu_ctx, oracle):
     assert np.array_equal(g['npivots'], g['iters'])
     p.set_anchor(None)
     assert_same(p.solve_batch(L, U, V), plain, 'anchor off')
+
+
+def _mixed_instance(n, m, seed):
+    """A random dense instance with the awkward ingredients mixed in: some fixed variables
+    (l == u), some infinite upper bounds, a few zero columns/rows."""
+    rng = np.random.default_rng(1000 + seed)
+    if m > 0:
+        A, b, c, l, u, _ = random_dense_milp_arrays(n, m, seed=seed)
+    else:
+        A, b = np.zeros((0, n)), np.zeros(0)
+        c = -rng.integers(1, 10, n).astype(float)
+        l, u = np.zeros(n), np.full(n, 10.0)
+    l, u = l.copy(), u.copy()
+    fixed = rng.random(n) < 0.1
+    u[fixed] = l[fixed] = np.floor(rng.uniform(0, 3, fixed.sum()))
+    u[(rng.random(n) < 0.15) & ~fixed] = INF
+    if m > 2:
+        A = A.copy()
+        A[rng.integers(0, m)] *= 0.0      # an empty row (b <= 0 keeps it feasible or not: either is fine)
+    return A, b, c, l, u
+
+
+@pytest.mark.parametrize('n,m', [(1, 1), (2, 1), (5, 0), (3, 40), (63, 31), (64, 32), (65, 33), (40, 33), (128, 64),
+                                 (129, 64), (100, 65), (255, 127), (256, 128), (256, 129), (200, 192), (256, 193),
+                                 (257, 100)])
+def test_tile_boundaries_and_edge_cases(n, m, gpu_ctx, oracle):
+    """Shapes on both sides of every tile limit (and the hand-over to the HBM-streaming kernel),
+    with fixed variables, infinite bounds and an empty row: cold roots, warm-started children,
+    truncated probes -- all bit-exact against the oracle."""
+    L, U, V = [], [], []
+    A, b, c, l, u = _mixed_instance(n, m, seed=n + m)
+    p = _ffi.Problem(gpu_ctx, A, b, c)
+    root = p.solve_batch(l[None], u[None])
+    o = oracle.lp_solve_batch(A, b, c, l[None], u[None])
+    assert_same(root, o, f'root {n}x{m} [{_ffi.kernel_name(m, n)}]')
+    if root['status'][0] not in (0, 2):
+        return
+    x = np.minimum(root['x'][0], 1e6)
+    frac = np.minimum(x - np.floor(x), np.ceil(x) - x)
+    for j in np.argsort(-frac, kind='stable')[:4]:
+        for side in (0, 1):
+            l2, u2 = l.copy(), u.copy()
+            if side == 0:
+                u2[j] = np.floor(x[j])
+            else:
+                l2[j] = np.ceil(x[j]) if frac[j] > 1e-9 else x[j] + 1
+            L.append(l2); U.append(u2); V.append(root['vstat'][0])
+    L, U, V = np.array(L), np.array(U), np.array(V)
+    for max_iter in (0, 3):
+        g = p.solve_batch(L, U, V, max_iter)
+        o = oracle.lp_solve_batch(A, b, c, L, U, V, max_iter)
+        assert_same(g, o, f'children {n}x{m} max_iter={max_iter}')
+    # a second generation from the first child that solved
+    ok = np.where(g['status'] == 0)[0]
+    if len(ok):
+        k = ok[0]
+        g0 = p.solve_batch(L[k:k + 1], U[k:k + 1], V[k:k + 1])
+        l3 = L[k].copy(); l3[np.argmax(frac)] = L[k][np.argmax(frac)]
+        gg = p.solve_batch(L, U, np.repeat(g0['vstat'], len(L), 0))
+        oo = oracle.lp_solve_batch(A, b, c, L, U, np.repeat(g0['vstat'], len(L), 0))
+        assert_same(gg, oo, f'cousins {n}x{m}')
