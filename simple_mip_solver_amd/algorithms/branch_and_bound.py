@@ -9,13 +9,16 @@ the MI355X engine.
 Deviations: wall-clock instead of CPU-clock time limits (GPU work does not advance
 time.process_time); the root dual bound used by the gap test is tracked incrementally instead of
 re-scanning every tree vertex up to four times per iteration (reference :199-213, :226-229) --
-same value, O(log N) instead of O(N); find_parameterized_dual_bound (:314-417) is out of scope.
+same value, O(log N) instead of O(N).
 """
 import heapq
 from queue import PriorityQueue
 import time
 
+import numpy as np
+
 from simple_mip_solver_amd.algorithms.base_algorithm import BaseAlgorithm
+from simple_mip_solver_amd.lp import Constraint, CyLPArray, DenseLP
 from simple_mip_solver_amd.nodes.base_node import BaseNode
 from simple_mip_solver_amd.utils.binary_tree import BinaryTree
 
@@ -312,6 +315,69 @@ class BranchAndBound(BaseAlgorithm):
         self._process_rtn(rtn)
 
     def find_parameterized_dual_bound(self, b):
-        raise NotImplementedError(
-            'find_parameterized_dual_bound (reference branch_and_bound.py:314-417) is outside '
-            'the node hot path this package accelerates; see DESIGN.md "out of scope"')
+        """Lower bound on the optimal value of the MILP at a new right-hand side b, from the dual
+        solutions stored along every leaf's lineage (reference :314-360): per leaf the best of
+        `y.b + max(d, 0).l + min(d, 0).u` over its solved ancestors and itself, then the worst
+        leaf.  Infeasible leaves are first re-solved with penalised slacks so that they carry a
+        finite dual solution (`_bound_parameterized_dual`).  Nodes that were never solved (pruned
+        by their inherited bound) contribute through their ancestors only."""
+        assert isinstance(b, CyLPArray), 'this function only works with CyLP arrays'
+        assert self.status != 'unsolved', 'must solve this instance before using this method'
+        assert self.frontier_batch is None, \
+            'the native frontier engine keeps no per-node duals; solve with frontier_batch=None'
+        terminal_nodes = self.tree.get_leaves(self.root_node.idx)
+        multi_const_nodes = [n.idx for n in terminal_nodes if len(n.lp.constraints) != 1]
+        assert not multi_const_nodes, \
+            f'This feature expects the root node to have a single constraint object and ' \
+            f'all nodes to branch by bounding variables instead of by adding constraints. ' \
+            f'It does not currently handle cuts being added after bounding. The following ' \
+            f'IDs belong to nodes that do not conform to these rules: {multi_const_nodes}'
+        assert all(b.shape == n.lp.constraints[0].lower.shape for n in terminal_nodes), \
+            'the shape of the RHS being added should match that of each node'
+        if self._swapped_constraint_direction:
+            b = -b
+            print('WARNING: your rhs was made negative to reflect constraints'
+                  ' flipping direction at instantiation')
+        for n in terminal_nodes:
+            if n.lp._status == 1:  # primal infeasible: bound its dual ray (once)
+                n.lp = self._bound_parameterized_dual(n.lp)
+        assert all(n.lp._status in [None, 0] for n in terminal_nodes)
+
+        def evaluate(lp):
+            d = np.concatenate(list(lp.dualVariableSolution.values()))
+            return float(np.inner(lp.dualConstraintSolution[lp.constraints[0].name], b) +
+                         np.inner(np.maximum(d, 0), lp.variablesLower) +
+                         np.inner(np.minimum(d, 0), lp.variablesUpper))
+
+        bounds = {}
+        for leaf in terminal_nodes:
+            solved = [n.lp for n in self.tree.get_node_instances(leaf.lineage) if n.lp._status == 0]
+            bounds[leaf.idx] = max(evaluate(lp) for lp in solved)
+        return min(bounds.values())
+
+    def _bound_parameterized_dual(self, cur_lp):
+        """The same LP with a slack block `s_i >= 0` on every constraint block i, priced at a
+        large M: its dual is the original dual with the multipliers capped at M, so a node with
+        an infeasible relaxation gets a finite (very large) dual solution to evaluate at other
+        right-hand sides (reference :362-417).  Solved before it is returned."""
+        assert isinstance(cur_lp, DenseLP), 'must give CyClpSimplex instance'
+        for i, constr in enumerate(cur_lp.constraints):
+            assert f's_{i}' not in [v.name for v in cur_lp.variables], \
+                f"variable 's_{i}' is a reserved name. please name your variable something else"
+        new_lp = DenseLP()
+        var_map = {v: new_lp.addVariable(v.name, v.dim) for v in cur_lp.variables}
+        n0 = cur_lp.nVariables
+        new_lp.variablesLower[:n0] = cur_lp.variablesLower
+        new_lp.variablesUpper[:n0] = cur_lp.variablesUpper
+        slacks = [new_lp.addVariable(f's_{i}', constr.rows) for i, constr in enumerate(cur_lp.constraints)]
+        for constr, s_i in zip(cur_lp.constraints, slacks):
+            extra = {var_map[v]: a for v, a in constr.varCoefs.items() if v is not constr.variables[0]}
+            extra[s_i] = np.identity(constr.rows)
+            new_lp.addConstraint(Constraint(var_map[constr.variables[0]], constr._coefs, constr.lower,
+                                            constr.upper, constr.name, extra))
+        new_lp.objective = np.concatenate([cur_lp.objective, np.full(new_lp.nVariables - n0, float(self._M))])
+        var_status, row_status = cur_lp.getBasisStatus()
+        # every s_i enters at its lower bound of 0 (status 3)
+        new_lp.setBasisStatus(np.concatenate([var_status, np.full(new_lp.nVariables - n0, 3)]), row_status)
+        new_lp.dual()
+        return new_lp

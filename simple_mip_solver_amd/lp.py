@@ -75,9 +75,23 @@ class Variable(_Bounded):
         self.name = name
         self.dim = int(dim)
         self._pending = None
+        self._lp = None      # the DenseLP the block belongs to, and its first column there
+        self._offset = 0
 
     def _fresh(self):
         return BoundSpec(self)
+
+    @property
+    def indices(self):
+        return np.arange(self._offset, self._offset + self.dim)
+
+    @property
+    def lower(self):
+        return self._lp.variablesLower[self._offset:self._offset + self.dim]
+
+    @property
+    def upper(self):
+        return self._lp.variablesUpper[self._offset:self._offset + self.dim]
 
     def __rmul__(self, coefs):
         return LinearExpression(self, coefs)
@@ -125,8 +139,12 @@ class Constraint:
     """A block of rows `lower <= coefs x <= upper`; mirrors the members read at
     base_node.py:104, :602-606 (`lower`, `upper`, `varCoefs`, `variables`, `name`)."""
 
-    def __init__(self, var, coefs, lower=None, upper=None, name=None):
-        self.variables = [var]
+    def __init__(self, var, coefs, lower=None, upper=None, name=None, extra=None):
+        # `extra`: coefficient blocks of further variable blocks {Variable: rows x dim}; the node
+        # hot path never has any (one block 'x'), the parametric dual bound adds slack blocks
+        self._extra = {} if not extra else {v: np.ascontiguousarray(a, dtype=np.float64)
+                                            for v, a in extra.items()}
+        self.variables = [var] + list(self._extra)
         self._coefs = np.ascontiguousarray(coefs, dtype=np.float64)
         self.rows = self._coefs.shape[0]
         self.lower = np.full(self.rows, -np.inf) if lower is None else _as_bound(lower, self.rows)
@@ -135,7 +153,16 @@ class Constraint:
 
     @property
     def varCoefs(self):
-        return {self.variables[0]: self._coefs}
+        return {self.variables[0]: self._coefs, **self._extra}
+
+    def dense(self, n):
+        """The rows over all n columns of the LP."""
+        if not self._extra and self._coefs.shape[1] == n:
+            return self._coefs
+        out = np.zeros((self.rows, n))
+        for v, a in self.varCoefs.items():
+            out[:, v._offset:v._offset + v.dim] = a
+        return out
 
     def __bool__(self):
         return True
@@ -243,6 +270,7 @@ class DenseLP:
         self._obj_value = None
         self._x = None
         self._row_duals = None
+        self._col_duals = None
         self._var_status = None   # Clp codes per column
         self._row_status = None   # Clp codes per row
         self._rowset = None       # cached engine form of the rows
@@ -252,6 +280,7 @@ class DenseLP:
     # ---- model building ------------------------------------------------------------------
     def addVariable(self, name, dim):
         v = Variable(name, dim)
+        v._lp, v._offset = self, self.nVariables
         self.variables.append(v)
         # Clp's defaults for a new column: 0 <= x <= +inf, zero cost
         self.variablesLower = np.concatenate([self.variablesLower, np.zeros(v.dim)])
@@ -284,7 +313,7 @@ class DenseLP:
             v._pending = None
         c = Constraint(constraint.variables[0], constraint._coefs, constraint.lower,
                        constraint.upper, name if name is not None else
-                       (constraint.name or f'R_{len(self.constraints)}'))
+                       (constraint.name or f'R_{len(self.constraints)}'), constraint._extra)
         self.constraints.append(c)
         if self._row_status is not None:
             # a new row enters with its slack basic, as Clp does
@@ -351,7 +380,7 @@ class DenseLP:
         n = self.nVariables
         if not self.constraints:
             return np.zeros((0, n))
-        return np.vstack([c._coefs for c in self.constraints])
+        return np.vstack([c.dense(n) for c in self.constraints])
 
     @staticmethod
     def getCoinInfinity():
@@ -379,15 +408,16 @@ class DenseLP:
             n = self.nVariables
             rows, rhs, rowmap = [], [], []
             for ci, c in enumerate(self.constraints):
+                full = c.dense(n)
                 for r in range(c.rows):
                     lo, up = c.lower[r], c.upper[r]
                     has_lo = lo > -COIN_INFINITY / 2 and not np.isneginf(lo)
                     has_up = up < COIN_INFINITY / 2 and not np.isposinf(up)
                     if has_lo or not has_up:
-                        rows.append(c._coefs[r]); rhs.append(lo if has_lo else -np.inf)
+                        rows.append(full[r]); rhs.append(lo if has_lo else -np.inf)
                         rowmap.append((ci, r, 1.0))
                     if has_up:
-                        rows.append(-c._coefs[r]); rhs.append(-up)
+                        rows.append(-full[r]); rhs.append(-up)
                         rowmap.append((ci, r, -1.0))
             A = np.array(rows, dtype=np.float64).reshape(len(rows), n)
             keep = [k for k, v in enumerate(rhs) if not np.isneginf(v)]  # free rows never bind
@@ -465,6 +495,9 @@ class DenseLP:
             duals[pos] += sign * y[e]
         self._row_status = row_status
         self._row_duals = duals
+        # reduced costs of the columns: d = c - A'y over the engine's rows
+        rs = self._rowset
+        self._col_duals = rs.c - rs.A.T @ y if rs.A.shape[0] else rs.c.copy()
 
     def getStatusCode(self):
         assert self._status is not None, 'LP has not been solved'
@@ -476,7 +509,14 @@ class DenseLP:
 
     @property
     def primalVariableSolution(self):
-        return {self.variables[0].name: self._x} if len(self.variables) == 1 else self._x
+        if len(self.variables) == 1:
+            return {self.variables[0].name: self._x}
+        return {v.name: self._x[v._offset:v._offset + v.dim] for v in self.variables}
+
+    @property
+    def dualVariableSolution(self):
+        """Reduced costs by variable block (CyClpSimplex.dualVariableSolution)."""
+        return {v.name: self._col_duals[v._offset:v._offset + v.dim] for v in self.variables}
 
     @property
     def dualConstraintSolution(self):
@@ -490,7 +530,9 @@ class DenseLP:
     def copy_with_bounds(self, lower, upper):
         """New LP sharing this one's rows and objective, with its own bounds and basis."""
         child = DenseLP()
+        assert len(self.variables) == 1, 'children are made of single-block LPs'
         child.variables = [Variable(v.name, v.dim) for v in self.variables]
+        child.variables[0]._lp = child
         vmap = dict(zip(self.variables, child.variables))
         child.constraints = [Constraint(vmap[c.variables[0]], c._coefs, c.lower, c.upper, c.name)
                              for c in self.constraints]

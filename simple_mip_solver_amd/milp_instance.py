@@ -125,3 +125,58 @@ def read_mps(path):
     assert kinds <= {'L'} or kinds <= {'G'}, 'rows must all be <= or all be >= (one sense per model)'
     sense = ['Min', '<=' if kinds <= {'L'} and kinds else '>=']
     return A, b, c, l, u, sense, sorted(integer)
+
+
+def write_mps(path, A, b, c, l, u, sense, integer_indices, name='mipx'):
+    """Write min/max c'x, Ax (<=|>=) b, l <= x <= u, x_I integer in the MPS subset the reference's
+    fixtures use (N/L/G rows, RHS, UP/UI/LO/FX/MI bounds; one sense per model), such that
+    `read_mps` returns the same arrays.  A 'Max' objective is written negated (MPS minimises)."""
+    A = np.asarray(A, dtype=np.float64)
+    A = A.reshape(-1, len(c)) if A.ndim != 2 else A
+    m, n = A.shape
+    b = np.asarray(b, dtype=np.float64).reshape(m)
+    c = np.asarray(c, dtype=np.float64).reshape(n)
+    c = c if sense[0] == 'Min' else -c
+    l = np.zeros(n) if l is None else np.asarray(l, dtype=np.float64).reshape(n)
+    u = np.full(n, COIN_INFINITY) if u is None else np.asarray(u, dtype=np.float64).reshape(n)
+    ints = set(int(i) for i in integer_indices)
+    kind = 'L' if sense[1] == '<=' else 'G'
+    num = lambda v: repr(float(v))
+    with open(path, 'w') as f:
+        f.write(f'NAME          {name}\nROWS\n N  OBJROW\n')
+        for i in range(m):
+            f.write(f' {kind}  R_{i}\n')
+        f.write('COLUMNS\n')
+        for j in range(n):
+            wrote = False
+            if c[j] != 0:
+                f.write(f'    x_{j}  OBJROW  {num(c[j])}\n')
+                wrote = True
+            for i in np.nonzero(A[:, j])[0]:
+                f.write(f'    x_{j}  R_{i}  {num(A[i, j])}\n')
+                wrote = True
+            if not wrote:  # a column must appear to exist
+                f.write(f'    x_{j}  OBJROW  0.0\n')
+        f.write('RHS\n')
+        for i in range(m):
+            if b[i] != 0:
+                f.write(f'    RHS  R_{i}  {num(b[i])}\n')
+        f.write('BOUNDS\n')
+        for j in range(n):
+            lo_inf, up_inf = l[j] <= -COIN_INFINITY / 2, u[j] >= COIN_INFINITY / 2
+            if j in ints:
+                # integrality travels on the bound type, as in the fixtures CyLP wrote (UI)
+                f.write(f' UI BOUND  x_{j}  {num(u[j] if not up_inf else COIN_INFINITY)}\n')
+                if l[j] != 0:
+                    f.write(f' {"MI" if lo_inf else "LO"} BOUND  x_{j}  {"" if lo_inf else num(l[j])}\n')
+                continue
+            if not lo_inf and not up_inf and l[j] == u[j]:
+                f.write(f' FX BOUND  x_{j}  {num(l[j])}\n')
+                continue
+            if lo_inf:
+                f.write(f' MI BOUND  x_{j}\n')
+            elif l[j] != 0:
+                f.write(f' LO BOUND  x_{j}  {num(l[j])}\n')
+            if not up_inf:
+                f.write(f' UP BOUND  x_{j}  {num(u[j])}\n')
+        f.write('ENDATA\n')

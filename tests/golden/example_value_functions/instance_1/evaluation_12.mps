@@ -1,0 +1,20 @@
+NAME          ClpDefau
+ROWS
+ N  OBJROW
+ L  R_262_0
+ L  R_262_1
+COLUMNS
+    x_0       OBJROW     -2.           R_262_1   20.         
+    x_1       OBJROW     -3.           R_262_0   14.         
+    x_1       R_262_1   38.         
+    x_2       OBJROW     -3.           R_262_0   28.         
+    x_2       R_262_1   33.         
+    x_3       OBJROW     -12.          R_262_1   29.         
+RHS
+    RHS       R_262_0   37.            R_262_1   14.         
+BOUNDS
+ UI BOUND     x_0       26.         
+ UI BOUND     x_1       26.         
+ UI BOUND     x_2       26.         
+ UI BOUND     x_3       26.         
+ENDATA

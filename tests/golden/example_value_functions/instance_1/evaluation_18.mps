@@ -1,0 +1,20 @@
+NAME          ClpDefau
+ROWS
+ N  OBJROW
+ L  R_286_0
+ L  R_286_1
+COLUMNS
+    x_0       OBJROW     -2.           R_286_1   20.         
+    x_1       OBJROW     -3.           R_286_0   14.         
+    x_1       R_286_1   38.         
+    x_2       OBJROW     -3.           R_286_0   28.         
+    x_2       R_286_1   33.         
+    x_3       OBJROW     -12.          R_286_1   29.         
+RHS
+    RHS       R_286_0   77.            R_286_1   60.         
+BOUNDS
+ UI BOUND     x_0       26.         
+ UI BOUND     x_1       26.         
+ UI BOUND     x_2       26.         
+ UI BOUND     x_3       26.         
+ENDATA

@@ -1,0 +1,20 @@
+NAME          ClpDefau
+ROWS
+ N  OBJROW
+ L  R_302_0
+ L  R_302_1
+COLUMNS
+    x_0       OBJROW     -2.           R_302_1   20.         
+    x_1       OBJROW     -3.           R_302_0   14.         
+    x_1       R_302_1   38.         
+    x_2       OBJROW     -3.           R_302_0   28.         
+    x_2       R_302_1   33.         
+    x_3       OBJROW     -12.          R_302_1   29.         
+RHS
+    RHS       R_302_0   12.            R_302_1   48.         
+BOUNDS
+ UI BOUND     x_0       26.         
+ UI BOUND     x_1       26.         
+ UI BOUND     x_2       26.         
+ UI BOUND     x_3       26.         
+ENDATA

@@ -1,0 +1,18 @@
+NAME          ClpDefau
+ROWS
+ N  OBJROW
+ L  R_826_0
+ L  R_826_1
+COLUMNS
+    x_0       OBJROW     -14.          R_826_0   11.         
+    x_1       OBJROW     -14.          R_826_1   39.         
+    x_2       OBJROW     -1.           R_826_0   3.          
+    x_3       OBJROW     -2.           R_826_0   28.         
+RHS
+    RHS       R_826_0   41.            R_826_1   29.         
+BOUNDS
+ UI BOUND     x_0       14.         
+ UI BOUND     x_1       14.         
+ UI BOUND     x_2       14.         
+ UI BOUND     x_3       14.         
+ENDATA

@@ -1,0 +1,18 @@
+NAME          ClpDefau
+ROWS
+ N  OBJROW
+ L  R_710_0
+ L  R_710_1
+COLUMNS
+    x_0       OBJROW     -14.          R_710_0   11.         
+    x_1       OBJROW     -14.          R_710_1   39.         
+    x_2       OBJROW     -1.           R_710_0   3.          
+    x_3       OBJROW     -2.           R_710_0   28.         
+RHS
+    RHS       R_710_0   42.            R_710_1   31.         
+BOUNDS
+ UI BOUND     x_0       14.         
+ UI BOUND     x_1       14.         
+ UI BOUND     x_2       14.         
+ UI BOUND     x_3       14.         
+ENDATA

@@ -267,6 +267,113 @@ def test_max_model_is_flipped(engine):
     assert bb.status == 'optimal' and bb.objective_value == -2
 
 
-def test_find_parameterized_dual_bound_is_out_of_scope(engine):
-    with pytest.raises(NotImplementedError, match='outside the node hot path'):
-        BranchAndBound(std_model('small_branch')).find_parameterized_dual_bound([1, 1])
+def test_find_parameterized_dual_bound_fails_asserts(engine):
+    from simple_mip_solver_amd import CyLPArray
+    bb = BranchAndBound(model('infeasible2'), gomory_cuts=False)
+    with pytest.raises(AssertionError, match='must solve this instance before'):
+        bb.find_parameterized_dual_bound(CyLPArray([2.5, 4.5]))
+    bb.solve()
+    with pytest.raises(AssertionError, match='only works with CyLP arrays'):
+        bb.find_parameterized_dual_bound(np.array([2.5, 4.5]))
+    with pytest.raises(AssertionError, match='shape of the RHS being added should match'):
+        bb.find_parameterized_dual_bound(CyLPArray([4.5]))
+    bb = BranchAndBound(model('infeasible2'), gomory_cuts=False)
+    bb.root_node.lp += np.array([[0, -1, -1]]) * bb.root_node.lp.getVarByName('x') >= CyLPArray([-2.5])
+    bb.solve()
+    with pytest.raises(AssertionError, match='feature expects the root node to have a single constraint object'):
+        bb.find_parameterized_dual_bound(CyLPArray([2.5, 4.5]))
+
+
+def test_find_parameterized_dual_bound(engine):
+    """The dual function of ISE 418 HW 3 problem 1 (reference test_branch_and_bound.py:533-575):
+    strong at the original right-hand side, the known values at beta = 0..5, always below the
+    re-solved optimum."""
+    from math import isclose
+    from simple_mip_solver_amd import CyLPArray
+    bb = BranchAndBound(model('h3p1'), gomory_cuts=False)
+    bb.solve()
+    assert bb.objective_value == bb.find_parameterized_dual_bound(CyLPArray([3.5, -3.5]))
+    sol_new = {0: 0, 1: 1, 2: 1, 3: 2, 4: 2, 5: 3}
+    sol_bound = {0: 0, 1: .5, 2: 1, 3: 2, 4: 2, 5: 2.5}
+    for beta in range(6):
+        new_bb = BranchAndBound(model(f'h3p1_{beta}'), gomory_cuts=False)
+        new_bb.solve()
+        bound = bb.find_parameterized_dual_bound(CyLPArray(np.array([beta, -beta])))
+        assert isclose(sol_new[beta], new_bb.objective_value, abs_tol=.01)
+        assert isclose(sol_bound[beta], bound, abs_tol=1e-9), (beta, bound)
+        assert bound <= new_bb.objective_value + .01
+
+    bb = BranchAndBound(std_model('small_branch'), gomory_cuts=False)
+    bb.solve()
+    assert bb.find_parameterized_dual_bound(CyLPArray([-2.5, -4.5])) <= -5.99
+
+    # infeasible leaves are re-bounded once, on the first call only
+    bb = BranchAndBound(std_model('small_branch'), gomory_cuts=False)
+    bb.solve()
+    infeasible = [n for n in bb.tree.get_leaves(0) if n.lp_feasible is False]
+    assert sorted(n.idx for n in infeasible) == [2, 6, 8, 10, 12]
+    with patch.object(bb, '_bound_parameterized_dual', wraps=bb._bound_parameterized_dual) as bd:
+        bb.find_parameterized_dual_bound(CyLPArray([3, 3]))
+        assert bd.call_count == 5
+    with patch.object(bb, '_bound_parameterized_dual') as bd:
+        bb.find_parameterized_dual_bound(CyLPArray([1, 1]))
+        assert not bd.called
+
+
+def test_bound_parameterized_dual(engine):
+    """reference test_branch_and_bound.py:602-660: same variables plus a slack block per
+    constraint block, same rows with an identity on the slacks, slacks priced at M."""
+    from simple_mip_solver_amd import CyLPArray
+    from simple_mip_solver_amd.lp import DenseLP
+    bb = BranchAndBound(model('infeasible2'), gomory_cuts=False)
+    bb.root_node.lp += np.array([[0, -1, -1]]) * bb.root_node.lp.getVarByName('x') >= CyLPArray([-2.5])
+    bb.solve()
+    n = [k for k in bb.tree.get_leaves(0) if k.lp_feasible is False][0]
+    with pytest.raises(AssertionError, match='must give CyClpSimplex instance'):
+        bb._bound_parameterized_dual(None)
+    lp = bb._bound_parameterized_dual(n.lp)
+    assert isinstance(lp, DenseLP)
+    assert {v.name for v in lp.variables} == {'x', 's_0', 's_1'}
+    old_x = n.lp.getVarByName('x')
+    new_x, s_0, s_1 = lp.getVarByName('x'), lp.getVarByName('s_0'), lp.getVarByName('s_1')
+    assert all(new_x.lower == old_x.lower) and all(new_x.upper == old_x.upper)
+    assert all(s_0.lower == [0, 0]) and all(s_0.upper > [1e300, 1e300])
+    assert all(s_1.lower == [0]) and all(s_1.upper > 1e300)
+    assert lp.nConstraints == 3
+    assert (lp.constraints[0].varCoefs[new_x] == np.array([[-1, -1, 0], [0, 0, -1]])).all()
+    assert (lp.constraints[0].varCoefs[s_0] == np.identity(2)).all()
+    assert all(lp.constraints[1].varCoefs[new_x][0] == np.array([0, -1, -1]))
+    assert lp.constraints[1].varCoefs[s_1] == np.identity(1)
+    assert all(lp.constraints[0].lower == np.array([1, -1])) and all(lp.constraints[0].upper >= 1e300)
+    assert lp.constraints[1].lower == np.array([-2.5]) and lp.constraints[1].upper >= 1e300
+    assert all(lp.objective == np.array([-1, -1, 0, bb._M, bb._M, bb._M]))
+    # solved, and feasible now that the slacks can absorb the infeasibility
+    assert lp.getStatusCode() == 0
+    n.lp.addVariable('s_0', 1)
+    with pytest.raises(AssertionError, match="variable 's_0' is a reserved name"):
+        bb._bound_parameterized_dual(n.lp)
+
+
+def test_find_parameterized_dual_bound_many_times(engine):
+    """The reference's value-function fixtures (test_branch_and_bound.py:577-600; a 5-instance
+    subset of test_simple_mip_solver/example_value_functions, 40 right-hand sides each): the dual
+    function of evaluation 0 never exceeds the optimum at any other right-hand side."""
+    import glob
+    import os
+    import re
+    from simple_mip_solver_amd import CyLPArray, MILPInstance
+    root = os.path.join(os.path.dirname(__file__), 'golden', 'example_value_functions')
+    folders = sorted(glob.glob(os.path.join(root, 'instance_*')))
+    assert len(folders) == 5
+    for folder in folders:
+        evals = {}
+        for f in glob.glob(os.path.join(folder, 'evaluation_*.mps')):
+            k = int(re.search(r'evaluation_(\d+).mps', f).group(1))
+            bb = BranchAndBound(MILPInstance(file_name=f), PseudoCostBranchNode, pseudo_costs={},
+                                gomory_cuts=False)
+            bb.solve()
+            evals[k] = bb
+        assert len(evals) == 40
+        for bb in evals.values():
+            # all problems were given as <=, so their constraints were flipped at instantiation
+            assert evals[0].find_parameterized_dual_bound(CyLPArray(-bb.model.b)) <= bb.objective_value + .01

@@ -109,3 +109,27 @@ def test_engine_form_handles_le_and_ranged_rows():
     lp.addConstraint(CyLPArray([1.0]) <= CyLPArray([1, -1]) * x <= CyLPArray([2.0]), 'rng')
     rs = lp._engine_form()
     assert np.array_equal(rs.A, [[-1, -1], [1, -1], [-1, 1]]) and all(rs.b == [-4, 1, -2])
+
+
+def test_mps_writer_round_trips_every_fixture(tmp_path):
+    """write_mps -> read_mps gives back the arrays of all 64 example models (the reference's
+    on-disk format, test_simple_mip_solver/example_models/*.mps), plus the awkward bound kinds."""
+    import glob
+    from simple_mip_solver_amd.milp_instance import read_mps, write_mps
+    files = sorted(glob.glob(os.path.join(GOLD, '*.mps')))
+    assert len(files) == 64
+    for k, f in enumerate(files):
+        A, b, c, l, u, sense, ints = read_mps(f)
+        out = tmp_path / f'rt_{k}.mps'
+        write_mps(out, A, b, c, l, u, sense, ints)
+        A2, b2, c2, l2, u2, sense2, ints2 = read_mps(out)
+        assert np.array_equal(A, A2) and np.array_equal(b, b2) and np.array_equal(c, c2), f
+        assert np.array_equal(l, l2) and np.array_equal(u, u2) and sense == sense2 and ints == ints2, f
+    A = np.array([[1.5, 0, -2], [0, 0, 1e-3]]); b = [0, -7.25]; c = [0, 3, -1e9]
+    l = [-np.inf, 2, 1]; u = [4, 2, np.inf]
+    out = tmp_path / 'odd.mps'
+    write_mps(out, A, b, c, l, u, ['Min', '>='], [2])
+    A2, b2, c2, l2, u2, sense2, ints2 = read_mps(out)
+    assert np.array_equal(A, A2) and np.array_equal(b2, b) and np.array_equal(c2, c)
+    assert l2[0] < -1e300 and l2[1] == u2[1] == 2 and l2[2] == 1 and u2[2] > 1e300 and u2[0] == 4
+    assert sense2 == ['Min', '>='] and ints2 == [2]
