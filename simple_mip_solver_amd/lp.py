@@ -255,7 +255,8 @@ class _RowSet:
 
 
 class DenseLP:
-    """Stand-in for CyClpSimplex restricted to what the node hot path uses."""
+    """Stand-in for CyClpSimplex restricted to what the node hot path uses (plus multi-block
+    models and free columns for the cut-generating LP)."""
 
     def __init__(self):
         self.logLevel = 0
@@ -439,16 +440,20 @@ class DenseLP:
         rstat = np.ones(len(self._rowmap), np.int8)
         for k, (ci, r, sign) in enumerate(self._rowmap):
             code = self._row_status[offsets[ci] + r] if self._row_status is not None else 1
-            # Clp's row status refers to the row activity: "at upper" of a <= row is its slack at 0
-            rstat[k] = 1 if code == 1 else 3
+            # Clp's row status refers to the row activity: "at upper" of a <= row is its slack at 0;
+            # of the two engine rows of a ranged / equality row only the tight side is nonbasic
+            tight = (code == 3 and sign > 0) or (code == 2 and sign < 0) or \
+                    (code not in (1, 2, 3))
+            rstat[k] = 3 if tight else 1
         return np.concatenate([self._var_status.astype(np.int8), rstat])[None]
 
     def dual(self):
         """Solve with the dual simplex engine (the reference's `lp.dual()`, base_node.py:273)."""
         rs = self._engine_form()
         l, u = self._bounds()
-        assert np.all(np.isfinite(l)), 'the engine needs finite lower bounds (x >= 0 on the hot path)'
         max_iter = int(self.maxNumIteration) if self.maxNumIteration else 0
+        if not np.all(np.isfinite(l)):
+            return self._dual_with_free_columns(rs, l, u, max_iter)
         # Re-solving an LP that has not changed since it was solved to optimality (same rows,
         # bounds and basis) is a no-op: the reference does exactly that once per fractional node
         # when a cut round adds nothing (base_node.py:317-319).  Keep the solution, skip the GPU.
@@ -463,6 +468,66 @@ class DenseLP:
         return self._status
 
     primal = dual  # the engine has one algorithm; results (status/objective/solution) are the same
+
+    FREE_BOX = (1e6, 1024.0)  # half-widths of the boxes put around columns without a bound
+
+    def _dual_with_free_columns(self, rs, l, u, max_iter):
+        """Columns without a lower bound (the cut-generating LP's pi, pi0) are outside the node
+        hot path, and the engine wants every l finite.  They are shifted into a finite box:
+        x_j = x'_j + centre_j - K (free) or x_j = u_j - x'_j (upper bound only), 0 <= x' <= 2K.
+        First a wide box around 0; then, warm-started from that basis, a narrow one around the
+        solution found, which removes the rounding the wide shift costs.  A box bound that is
+        active at the optimum with a nonzero reduced cost means the LP is unbounded in that
+        direction: status 2."""
+        m_e, n = rs.A.shape
+        kinds = np.where(np.isfinite(l), 0, np.where(np.isfinite(u), 1, 2))
+        k1, k2 = kinds == 1, kinds == 2
+
+        def solve_boxed(centre, K, ws):
+            A_e, c_e = rs.A.copy(), rs.c.copy()
+            lo, up = l.copy(), u.copy()
+            # x = shift + sgn * x'
+            shift = np.where(k1, u, np.where(k2, centre - K, 0.0))
+            A_e[:, k1] *= -1.0
+            c_e[k1] *= -1.0
+            b_e = rs.b - rs.A[:, kinds != 0] @ shift[kinds != 0]
+            offset = float(rs.c[kinds != 0] @ shift[kinds != 0])
+            lo[kinds != 0], up[kinds != 0] = 0.0, 2.0 * K
+            gen_rs = _RowSet(A_e, b_e, c_e)
+            res = get_backend().solve(gen_rs.A, gen_rs.b, gen_rs.c, lo[None], up[None], ws, max_iter,
+                                      gen_rs.key)
+            xe = np.asarray(res['x'][0], dtype=np.float64)
+            ve = np.asarray(res['vstat'][0], np.int8)
+            x = np.where(k1, u - xe, np.where(k2, xe + centre - K, xe))
+            y = np.asarray(res['y'][0], dtype=np.float64)
+            d = rs.c - rs.A.T @ y if m_e else rs.c.copy()
+            status = int(res['status'][0])
+            stuck = (kinds != 0) & (ve[:n] != 1) & ((xe >= 2.0 * K) | (k2 & (xe <= 0.0))) & (np.abs(d) > 1e-7)
+            return dict(status=status, stuck=bool(np.any(stuck)), x=x, y=y, ve=ve,
+                        obj=float(res['obj'][0]) + offset, iters=int(res['iters'][0]))
+
+        ws = None
+        if self._var_status is not None:
+            ws = self._warm_start(rs)[0].copy()
+            ws[:n][k1] = np.where(ws[:n][k1] == 1, 1, np.where(ws[:n][k1] == 2, 3, 2))
+            ws = ws[None]
+        first = solve_boxed(np.zeros(n), float(self.FREE_BOX[0]), ws)
+        out = first
+        if first['status'] == 0 and not first['stuck'] and max_iter == 0:
+            second = solve_boxed(np.round(first['x']), float(self.FREE_BOX[1]), first['ve'][None])
+            if second['status'] == 0 and not second['stuck']:
+                second['iters'] += first['iters']
+                out = second
+        status = 2 if (out['status'] == 0 and out['stuck']) else out['status']
+        ve = out['ve']
+        vs = ve[:n].copy()
+        vs[k1] = np.where(ve[:n][k1] == 1, 1, np.where(ve[:n][k1] == 2, 3, 2))
+        mapped = dict(status=np.array([status]), obj=np.array([out['obj']]), x=out['x'][None],
+                      y=out['y'][None], iters=np.array([out['iters']]),
+                      vstat=np.concatenate([vs, ve[n:]])[None])
+        self._store(mapped, 0)
+        self._solved_sig = None
+        return self._status
 
     def gomory_rows(self, x, integer_indices, max_term):
         """GMI cuts of the current (optimal) basis from the engine's cut kernel, in the LP's own

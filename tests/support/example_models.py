@@ -23,6 +23,7 @@ _MODELS = {
              ['Min', '>='], [0, 1]),
     'square': (-np.eye(2), [-1.5, -1.5], [-1, -1], [0, 0], None, ['Min', '>='], [0, 1]),
     'negative': (-np.eye(2), [.5, -.5], [-1, -1], [-1, -1], None, ['Min', '>='], [0, 1]),
+    'lift_project': ([[-1, 1], [1, 1]], [-1, 2], [1, 2], [0, 0], None, ['Min', '>='], [0, 1]),
     # ISE 418 HW 3 problem 1 and its right-hand-side family (example_models.py:195-278)
     'h3p1': ([[2, 5, -2, -2, 5, 5], [-2, -5, 2, 2, -5, -5]], [3.5, -3.5], [1, 4, 6, 4, 5, 7], [0] * 6, None,
              ['Min', '>='], [0, 1, 3]),

@@ -63,3 +63,31 @@ def test_models_with_gomory_cuts(engine, Node):
             f'{f}: {bb.objective_value} vs HiGHS {rec["milp_opt"]}'
         check_pseudo_costs(bb)
         check_gmics(bb)
+
+
+@pytest.mark.parametrize('kwargs', [
+    dict(cglp_cumulative_constraints=cc, cglp_cumulative_bounds=cb, gomory_cuts=gc, warm_start_cglp=ws,
+         max_cglp_calls=mc)
+    for cc, cb, gc, ws, mc in [(True, True, True, True, 1), (False, False, False, True, None),
+                               (True, False, False, False, 1), (False, True, True, True, None),
+                               (False, False, True, False, None)]])
+def test_models_with_disjunctive_cuts(engine, kwargs):
+    """helpers.TestModels.disjunctive_cut_test_models (helpers.py:75-131) on a fixed third of the
+    models and five of its keyword combinations: a CGLP from an 8-node tree, then the full solve
+    with DisjunctiveCutBoundPseudoCostBranchNode; optimum within the reference's abs_tol=.01."""
+    from simple_mip_solver_amd import DisjunctiveCutBoundPseudoCostBranchNode
+    from simple_mip_solver_amd.utils.cut_generating_lp import CutGeneratingLP
+    for k, (f, rec) in enumerate(sorted(TABLE.items())):
+        if k % 3 or k == 3:   # (the reference skips its model 3 too: a bad GMIC)
+            continue
+        m = MILPInstance(file_name=os.path.join(HERE, 'golden', 'example_models', f))
+        cglp_bb = BranchAndBound(m, node_limit=8, gomory_cuts=kwargs['gomory_cuts'])
+        cglp_bb.solve()
+        cglp = CutGeneratingLP(cglp_bb, cglp_bb.root_node.idx)
+        bb = BranchAndBound(m, DisjunctiveCutBoundPseudoCostBranchNode, cglp=cglp, pseudo_costs={}, **kwargs)
+        bb.solve()
+        assert bb.status == 'optimal', f
+        assert isclose(bb.objective_value, rec['milp_opt'], abs_tol=.01), \
+            f'{f} {kwargs}: {bb.objective_value} vs HiGHS {rec["milp_opt"]}'
+        check_pseudo_costs(bb)
+        check_gmics(bb)
