@@ -33,6 +33,9 @@ from simple_mip_solver_amd.generators import random_dense_milp_arrays  # noqa: E
 from simple_mip_solver_amd.parallel import PseudoCostExchange, exchange, global_gap  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+# f64 vector FMA: half the guide's 157.3 TFLOP/s f32 vector rate; scripts/microbench/prim.hip measures
+# 64 dependent-free v_fma_f64 in 278 cycles per wave = 72 TFLOP/s over 1024 SIMDs at 2.4 GHz
+F64_VECTOR_PEAK_TFLOPS = 78.6
 
 
 def algorithmic_bytes(m, n, lps, pivots):
@@ -64,7 +67,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist, device = None, 'cpu'
     gpu_index = local_rank
-    if world > 1:
+    if world > 1 or os.environ.get('MIPX_BENCH_FORCE_DIST'):  # the env: RCCL path with one rank
         import torch
         import torch.distributed as dist_
         dist = dist_
@@ -141,17 +144,21 @@ def main():
             anchor_cm = O.anchored(O.make_anchor(A, b, c, root['vstat']))
         deadline = time.perf_counter() + args.cpu_seconds
         tc = time.perf_counter()
+        done, passes = 0, 0
         with anchor_cm, ThreadPoolExecutor(threads) as ex:
-            done_chunks = list(ex.map(work, range(nchunks)))
+            # whole passes over the peeked nodes until about cpu_seconds x 2 of CPU work is done
+            while passes == 0 or ((time.perf_counter() - tc) * threads < 2 * args.cpu_seconds
+                                  and time.perf_counter() < deadline):
+                done += int(sum(ex.map(work, range(nchunks))))
+                passes += 1
         t_cpu = time.perf_counter() - tc
-        done = int(sum(done_chunks))
         model = ''
         try:
             model = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
         except Exception:
             pass
         cpu = {'value': done / t_cpu, 'unit': 'node LP-relaxations/s', 'cores': threads, 'kind': 'port',
-               'sample': f'{done} open nodes of the same tree (the LPs the GPU solves next: bounds + '
+               'sample': f'{done} node LPs = {passes} pass(es) over {len(L)} open nodes of the same tree (the LPs the GPU solves next: bounds + '
                          f'warm-start bases read back from the device pool), oracle/libmipx_oracle.so '
                          f'({"anchored at the root tableau like the GPU path" if not args.no_anchor else "slack-basis refactorisation"}), '
                          f'{threads} threads over nodes, {t_cpu:.1f} s wall; host: {os.cpu_count()} logical '
@@ -240,6 +247,13 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'launch_ms': launch_s * 1e3,
+                         'vector_f64': {'achieved': 2.0 * m * n * d['pivots'] / args.steps / launch_s / 1e12,
+                                        'peak': F64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                        'frac': 2.0 * m * n * d['pivots'] / args.steps / launch_s / 1e12
+                                                / F64_VECTOR_PEAK_TFLOPS,
+                                        'note': 'rank-1 tableau updates (2mn flop per pivot) against the '
+                                                'v_fma_f64 rate: the kernel is bound by the dependent '
+                                                'selection chains between the updates, not by either roof'},
                          'note': 'algorithmic bytes of the dense-tableau HBM model (SURVEY 8d) over '
                                  'the node-LP kernel time (HIP events on its stream), rank 0; the '
                                  'tableau is register-resident, so real HBM traffic is far below'},
