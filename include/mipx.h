@@ -39,6 +39,7 @@ extern "C" {
 #define MIPX_EHIP -3      /* HIP runtime error (see mipx_last_error) */
 #define MIPX_ETOOBIG -4   /* (m, n) exceeds what the on-chip tableau kernels support */
 #define MIPX_ENOMEM -5
+#define MIPX_EHOOK -6     /* a step hook asked mipx_tree_solve to stop */
 
 typedef struct mipx_ctx mipx_ctx;
 typedef struct mipx_problem mipx_problem;
@@ -223,6 +224,15 @@ int mipx_tree_pseudo_costs(mipx_tree *t, double *cost_l, double *cost_r, int32_t
  * (PseudoCostBranchNode.pseudo_costs shared through _kwargs, branch/pseudo_cost.py:38-43). */
 int mipx_tree_set_pseudo_costs(mipx_tree *t, const double *cost_l, const double *cost_r,
                                const int32_t *times_l, const int32_t *times_r);
+/* Step hook: `fn(user)` is called on the calling thread every `every_steps` frontier steps of
+ * mipx_tree_solve, after the next step's kernels are queued and before the host waits for the
+ * current one -- the slot in which a multi-GPU rank runs its incumbent / bound / pseudo-cost
+ * all-reduce without draining the launch pipeline.  Inside the hook the tree may be
+ * read (get_stats, pseudo_costs) and mipx_tree_set_primal_bound / mipx_tree_set_pseudo_costs may be
+ * called; a nonzero return ends the solve with MIPX_EHOOK.  fn = NULL removes the hook.  The
+ * reference has no counterpart (single process). */
+typedef int (*mipx_tree_hook)(void *user);
+int mipx_tree_set_step_hook(mipx_tree *t, mipx_tree_hook fn, void *user, int every_steps);
 /* Copy the records of up to max_nodes open nodes (queue-array order) to HOST buffers without
  * removing them: l, u (max_nodes x n), vstat (max_nodes x (n+m)), dual_bound (max_nodes); any may
  * be NULL.  Returns the number copied (used by bench.py to time the CPU oracle on the very LPs the

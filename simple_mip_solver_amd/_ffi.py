@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MIPX_LIB') or os.path.join(_HERE, 'csrc', 'libmipx.so
 
 MIPX_OK = 0
 ERRORS = {-1: 'MIPX_EINVAL', -2: 'MIPX_ENODEV', -3: 'MIPX_EHIP', -4: 'MIPX_ETOOBIG',
-          -5: 'MIPX_ENOMEM'}
+          -5: 'MIPX_ENOMEM', -6: 'MIPX_EHOOK'}
 
 # every symbol include/mipx.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -25,6 +25,7 @@ SYMBOLS = [
     'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
     'mipx_tree_solution', 'mipx_tree_set_primal_bound', 'mipx_tree_pseudo_costs', 'mipx_tree_set_pseudo_costs',
     'mipx_tree_set_trace', 'mipx_tree_trace', 'mipx_tree_peek_open', 'mipx_tree_keep_shard',
+    'mipx_tree_set_step_hook',
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -327,8 +328,33 @@ class Tree:
         rc = lib().mipx_tree_solve(self._h, int(node_limit), float(mip_gap), float(max_seconds),
                                    int(frontier_batch or self.max_batch), int(max_steps),
                                    C.byref(st))
+        err, self._hook_error = getattr(self, '_hook_error', None), None
+        if err is not None:  # raised inside the step hook: the engine stopped, re-raise it here
+            raise err
         self.problem.ctx.check(rc, 'mipx_tree_solve')
         return st.as_dict()
+
+    def set_step_hook(self, fn, every_steps=1):
+        """Call fn() every `every_steps` frontier steps inside solve(), while the GPU works on the
+        steps already queued (mipx_tree_set_step_hook): the place for a rank's all-reduce.  fn may
+        use stats(), pseudo_cost_arrays(), set_primal_bound(), set_pseudo_cost_arrays(); a truthy
+        return value or an exception stops the solve.  fn=None removes the hook."""
+        L = lib()
+        proto = C.CFUNCTYPE(C.c_int, _vp)
+        L.mipx_tree_set_step_hook.argtypes = [_vp, proto, _vp, C.c_int]
+        if fn is None:
+            self._hook = None
+            rc = L.mipx_tree_set_step_hook(self._h, proto(), None, 0)
+        else:
+            def trampoline(_user):
+                try:
+                    return 1 if fn() else 0
+                except BaseException as e:  # never unwind through the C frames
+                    self._hook_error = e
+                    return 1
+            self._hook = proto(trampoline)  # keep the thunk alive as long as it is installed
+            rc = L.mipx_tree_set_step_hook(self._h, self._hook, None, int(every_steps))
+        self.problem.ctx.check(rc, 'mipx_tree_set_step_hook')
 
     def stats(self):
         st = TreeStats()

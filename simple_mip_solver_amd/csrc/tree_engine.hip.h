@@ -143,6 +143,9 @@ struct BucketQueue {
 struct StepBuf {
     int32_t *d_slot = nullptr, *d_status = nullptr, *d_iters = nullptr, *d_npiv = nullptr,
             *d_bidx = nullptr, *d_mipf = nullptr, *d_nprobe = nullptr, *d_plist = nullptr;
+    int32_t *d_ask_count = nullptr;          // [count | pad] then kAskCap entries, inside d_pack
+    mipx::ScoreArgs::Ask *d_ask = nullptr;
+    size_t ask_off = 0;
     double *d_obj = nullptr, *d_x = nullptr, *d_bval = nullptr;
     int8_t *d_vout = nullptr;
     // what the host reads back every step, packed so that ONE copy into pinned memory fetches it:
@@ -175,8 +178,12 @@ struct mipx_tree {
     hipEvent_t ev_child = nullptr;
     bool child_pending = false;
     int32_t *h_pairs = nullptr; // pinned staging of the branching lists
+    char *h_pres = nullptr;     // pinned mirror of the probe results [pp_obj | pp_status]
     StepBuf buf[2];
     bool table_dirty = false, pipeline = true;
+    mipx_tree_hook hook = nullptr;
+    void *hook_user = nullptr;
+    int hook_every = 0;
     // probe pool (strong branching)
     int64_t probe_cap = 0;
     double *pp_l = nullptr, *pp_u = nullptr, *pp_obj = nullptr;
@@ -208,7 +215,8 @@ struct mipx_tree {
     std::vector<double> tr_obj;
     bool trace = false;
     bool anchor_mode = false, anchor_set = false;
-    double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // MIPX_TREE_PROFILE=1: host-side breakdown
+    double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double probe_ms[4] = {0, 0, 0, 0};  // probes phase: read-back of askers | enqueue | wait | results  // MIPX_TREE_PROFILE=1: host-side breakdown
 };
 
 namespace {
@@ -278,6 +286,18 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
     return launch_lp_any(t->prob, a, batch, stream);
 }
 
+// Device -> host copies of the step loop go through the side stream, never the null stream: a
+// null-stream copy shares a hardware queue with whatever the runtime mapped there, and in a
+// process that also runs torch + RCCL that was the main stream with a 2 ms node-LP launch queued
+// (measured: ~1 ms per synchronous hipMemcpy, 18 ms per 20 steps).
+int tree_d2h(mipx_tree *t, void *dst, const void *src, size_t bytes) {
+    HIP_TRY(t->ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, t->st2));
+    HIP_TRY(t->ctx, hipStreamSynchronize(t->st2));
+    return MIPX_OK;
+}
+
+constexpr int kAskCap = 2048;  // probe requests per step carried in the packed read-back
+
 int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false) {
     mipx::ScoreArgs s;
     s.n = t->n; s.n_int = t->n_int; s.batch = batch; s.rule = t->rule;
@@ -287,6 +307,8 @@ int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false) {
     s.branch_idx = S.d_bidx; s.branch_val = S.d_bval; s.mip_feasible = S.d_mipf;
     s.n_probe = S.d_nprobe;
     s.probe_list = S.d_plist;
+    s.ask_count = S.d_ask_count; s.ask_cap = kAskCap; s.ask = side ? nullptr : S.d_ask;
+    if (!side) HIP_TRY(t->ctx, hipMemsetAsync(S.d_ask_count, 0, 16, t->ctx->stream));
     hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, side ? t->st2 : t->ctx->stream, s);
     HIP_TRY(t->ctx, hipGetLastError());
     return MIPX_OK;
@@ -393,7 +415,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         if (hipEventElapsedTime(&ms, S.e0, S.e1) == hipSuccess) t->kernel_ms += ms;
     }
     // one copy (pinned destination) for everything the host reads per node
-    HIP_TRY(ctx, hipMemcpy(S.h_pack, S.d_pack, S.pack_bytes, hipMemcpyDeviceToHost));
+    if ((rc = tree_d2h(t, S.h_pack, S.d_pack, S.pack_bytes))) return rc;
     const size_t MB = (size_t)t->max_batch;
     double *obj = (double *)S.h_pack, *bval = obj + MB;
     int32_t *status = (int32_t *)(bval + MB), *bidx = status + MB, *mipf = bidx + MB, *nprobe = mipf + MB,
@@ -416,35 +438,41 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         hipStream_t ps = use_side ? t->st2 : st;
         if (total > 0) {
             if (2 * total > t->probe_cap) return fail(ctx, MIPX_ENOMEM, "tree: probe pool exhausted");
-            // probe lists and the probed values: read back only the rows of the nodes that asked
-            // (a handful per step once the table has filled), in bulk during the ramp-up
-            int askers = 0;
-            for (int k = 0; k < B; k++) askers += nprobe[k] > 0;
-            std::vector<double> xall;
-            plist.resize((size_t)B * t->n_int);
-            const bool bulk = askers > 64;
-            if (bulk) {
+            // The probe requests came with the packed read-back (K4 writes one compact entry per
+            // request); only a step with more than kAskCap of them -- the ramp-up -- reads the
+            // per-node lists and solutions in bulk.
+            const int32_t asked = *(const int32_t *)(S.h_pack + S.ask_off);
+            if (asked == total && asked <= kAskCap) {
+                using Ask = mipx::ScoreArgs::Ask;
+                const Ask *ask = (const Ask *)(S.h_pack + S.ask_off + 16);
+                std::vector<Ask> es(ask, ask + asked);
+                std::sort(es.begin(), es.end(), [](const Ask &a, const Ask &b) {
+                    return a.node < b.node || (a.node == b.node && a.k < b.k);
+                });
+                for (const Ask &e : es) {
+                    pair_pos.push_back(e.node);
+                    pair_slot.push_back(slots[e.node]);
+                    pair_var.push_back(t->int_idx[e.k]);
+                    xrow.push_back(e.x);
+                }
+            } else {
+                std::vector<double> xall((size_t)B * n);
+                plist.resize((size_t)B * t->n_int);
                 HIP_TRY(ctx, hipMemcpy(plist.data(), S.d_plist, plist.size() * 4, hipMemcpyDeviceToHost));
-                xall.resize((size_t)B * n);
                 HIP_TRY(ctx, hipMemcpy(xall.data(), S.d_x, xall.size() * 8, hipMemcpyDeviceToHost));
-            }
-            std::vector<double> xone(n);
-            for (int k = 0; k < B; k++) {
-                if (!nprobe[k]) continue;
-                if (!bulk) {
-                    HIP_TRY(ctx, hipMemcpy(plist.data() + (size_t)k * t->n_int, S.d_plist + (size_t)k * t->n_int,
-                                           (size_t)nprobe[k] * 4, hipMemcpyDeviceToHost));
-                    HIP_TRY(ctx, hipMemcpy(xone.data(), S.d_x + (size_t)k * n, (size_t)n * 8, hipMemcpyDeviceToHost));
-                }
-                const double *xk = bulk ? xall.data() + (size_t)k * n : xone.data();
-                for (int e = 0; e < nprobe[k]; e++) {
-                    const int var = t->int_idx[plist[(size_t)k * t->n_int + e]];
-                    pair_pos.push_back(k);
-                    pair_slot.push_back(slots[k]);
-                    pair_var.push_back(var);
-                    xrow.push_back(xk[var]);
+                for (int k = 0; k < B; k++) {
+                    const double *xk = xall.data() + (size_t)k * n;
+                    for (int e = 0; e < nprobe[k]; e++) {
+                        const int var = t->int_idx[plist[(size_t)k * t->n_int + e]];
+                        pair_pos.push_back(k);
+                        pair_slot.push_back(slots[k]);
+                        pair_var.push_back(var);
+                        xrow.push_back(xk[var]);
+                    }
                 }
             }
+            auto tq = now();
+            t->probe_ms[0] += ms_since(tp);
             const int P = (int)pair_pos.size();
             child_slot.resize(2 * (size_t)P);
             for (int c = 0; c < 2 * P; c++) child_slot[c] = c;
@@ -470,9 +498,14 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             if (rc) return rc;
             pst.resize(2 * (size_t)P);
             pobj.resize(2 * (size_t)P);
+            t->probe_ms[1] += ms_since(tq); tq = now();
             HIP_TRY(ctx, hipStreamSynchronize(ps));
-            HIP_TRY(ctx, hipMemcpy(pst.data(), t->pp_status, pst.size() * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(ctx, hipMemcpy(pobj.data(), t->pp_obj, pobj.size() * 8, hipMemcpyDeviceToHost));
+            t->probe_ms[2] += ms_since(tq); tq = now();
+            HIP_TRY(ctx, hipMemcpyAsync(t->h_pres, t->pp_obj, pobj.size() * 8, hipMemcpyDeviceToHost, t->st2));
+            if ((rc = tree_d2h(t, t->h_pres + (size_t)t->probe_cap * 8, t->pp_status, pst.size() * 4))) return rc;
+            std::memcpy(pobj.data(), t->h_pres, pobj.size() * 8);
+            std::memcpy(pst.data(), t->h_pres + (size_t)t->probe_cap * 8, pst.size() * 4);
+            t->probe_ms[3] += ms_since(tq);
             t->probes += 2 * P;
         }
         t->phase_ms[5] += ms_since(tp); tp = now();
@@ -518,8 +551,8 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             if (!use_side) t->table_dirty = false;
             if ((rc = launch_score(t, S, B, use_side))) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ps));
-            HIP_TRY(ctx, hipMemcpy(bidx, S.d_bidx, (size_t)B * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(ctx, hipMemcpy(bval, S.d_bval, (size_t)B * 8, hipMemcpyDeviceToHost));
+            if ((rc = tree_d2h(t, bidx, S.d_bidx, (size_t)B * 4))) return rc;
+            if ((rc = tree_d2h(t, bval, S.d_bval, (size_t)B * 8))) return rc;
         }
     }
 
@@ -569,8 +602,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     }
     if (incumbent_pos >= 0) {
         // the last improving node of the batch holds the incumbent
-        HIP_TRY(ctx, hipMemcpy(t->best_x.data(), S.d_x + (size_t)incumbent_pos * n, (size_t)n * 8,
-                               hipMemcpyDeviceToHost));
+        if ((rc = tree_d2h(t, t->best_x.data(), S.d_x + (size_t)incumbent_pos * n, (size_t)n * 8))) return rc;
         t->have_x = true;
     }
     t->phase_ms[3] += ms_since(tp); tp = now();
@@ -654,14 +686,22 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     rc |= dmalloc(ctx, &t->d_pairs, 5 * (pc / 2 > B ? pc / 2 : B));
     rc |= dmalloc(ctx, &t->d_pairs2, 5 * (pc / 2 > B ? pc / 2 : B));
     rc |= dmalloc(ctx, &t->d_cost_l2, n); rc |= dmalloc(ctx, &t->d_cost_r2, n); rc |= dmalloc(ctx, &t->d_has2, n);
-    if (hipStreamCreateWithFlags(&t->st2, hipStreamNonBlocking) != hipSuccess) rc |= MIPX_EHIP;
-    if (hipStreamCreateWithFlags(&t->st3, hipStreamNonBlocking) != hipSuccess ||
+    // The side streams carry short, latency-critical work (probes, re-scoring, child records) that
+    // must overtake the 2 ms node-LP launch queued on the main stream.  HIP multiplexes the streams
+    // of one priority onto a few hardware queues, so in a process that owns more streams (torch +
+    // RCCL in a multi-GPU rank) a normal-priority side stream can land behind the main stream's
+    // queue; high-priority streams come from their own queue pool.
+    int prio_least = 0, prio_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_greatest = 0;
+    if (hipStreamCreateWithPriority(&t->st2, hipStreamNonBlocking, prio_greatest) != hipSuccess) rc |= MIPX_EHIP;
+    if (hipStreamCreateWithPriority(&t->st3, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&t->ev_child, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&t->h_pairs, 5 * B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
     for (StepBuf &S : t->buf) {
         rc |= dmalloc(ctx, &S.d_slot, B);
         rc |= dmalloc(ctx, &S.d_iters, B);
-        S.pack_bytes = B * (2 * 8 + 5 * 4);
+        S.ask_off = (B * (2 * 8 + 5 * 4) + 15) / 16 * 16;
+        S.pack_bytes = S.ask_off + 16 + (size_t)kAskCap * sizeof(mipx::ScoreArgs::Ask);
         rc |= dmalloc(ctx, &S.d_pack, S.pack_bytes);
         if (hipHostMalloc((void **)&S.h_pack, S.pack_bytes, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc((void **)&S.h_slot, B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
@@ -669,6 +709,8 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
             S.d_obj = (double *)S.d_pack; S.d_bval = S.d_obj + B;
             S.d_status = (int32_t *)(S.d_bval + B); S.d_bidx = S.d_status + B; S.d_mipf = S.d_bidx + B;
             S.d_nprobe = S.d_mipf + B; S.d_npiv = S.d_nprobe + B;
+            S.d_ask_count = (int32_t *)((char *)S.d_pack + S.ask_off);
+            S.d_ask = (mipx::ScoreArgs::Ask *)((char *)S.d_pack + S.ask_off + 16);
         }
         rc |= dmalloc(ctx, &S.d_plist, B * (size_t)(n_int ? n_int : 1));
         rc |= dmalloc(ctx, &S.d_x, B * n);
@@ -682,6 +724,7 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
         rc |= dmalloc(ctx, &t->pp_l, pc * n); rc |= dmalloc(ctx, &t->pp_u, pc * n);
         rc |= dmalloc(ctx, &t->pp_v, pc * nv); rc |= dmalloc(ctx, &t->pp_obj, pc);
         rc |= dmalloc(ctx, &t->pp_status, pc);
+        if (hipHostMalloc((void **)&t->h_pres, pc * 12, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
     }
     if (rc) { mipx_tree_destroy(t); return MIPX_EHIP; }
     t->cost_l.assign(n, 0.0); t->cost_r.assign(n, 0.0);
@@ -719,6 +762,7 @@ void mipx_tree_destroy(mipx_tree *t) {
     if (t->st3) { (void)hipStreamSynchronize(t->st3); (void)hipStreamDestroy(t->st3); }
     if (t->ev_child) (void)hipEventDestroy(t->ev_child);
     if (t->h_pairs) (void)hipHostFree(t->h_pairs);
+    if (t->h_pres) (void)hipHostFree(t->h_pres);
     void *ptrs[] = {t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_pairs, t->d_pairs2, t->d_cost_l,
                     t->d_cost_r, t->d_has, t->d_cost_l2, t->d_cost_r2, t->d_has2, t->pp_l, t->pp_u, t->pp_v, t->pp_obj, t->pp_status};
     for (void *q : ptrs)
@@ -766,20 +810,22 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const auto t0 = std::chrono::steady_clock::now();
     const double inf = std::numeric_limits<double>::infinity();
-    double ph0[8];
+    double ph0[8], pr0[4];
     for (int k = 0; k < 8; k++) ph0[k] = t->phase_ms[k];
+    for (int k = 0; k < 4; k++) pr0[k] = t->probe_ms[k];
     const double k0 = t->kernel_ms;
     if (!t->started) {
         t->started = true;
         tree_push(t, 0);
     }
-    int64_t steps = 0;
+    int64_t steps = 0, hooked_at = 0;
+    bool hook_stop = false;
     // With frontier batches > 1 the host half of step k (bookkeeping, children) overlaps the GPU
     // half of step k+1, whose batch is popped before the children of step k exist.
     const bool overlap = t->pipeline && frontier_batch > 1;
     int cur = 0;
     auto stop_now = [&](int64_t inflight) {
-        if (t->unbounded) return true;
+        if (t->unbounded || hook_stop) return true;
         if (node_limit > 0 && t->evaluated + inflight >= node_limit) return true;
         const double gap = tree_gap(t);
         if (gap >= 0 && gap <= mip_gap) return true;
@@ -809,6 +855,10 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
                 if (N.in_flight) steps++;
             }
         }
+        if (t->hook && steps > 0 && steps % t->hook_every == 0 && steps != hooked_at) {
+            hooked_at = steps;  // the GPU is busy with the queued steps while the ranks exchange
+            if (t->hook(t->hook_user)) hook_stop = true;
+        }
         int rc = tree_finish(t, S, overlap);
         if (rc) return rc;
         if (!N.in_flight && !tree_queue_empty(t) && !stop_now(0)) {
@@ -828,13 +878,24 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
                      t->phase_ms[0] - ph0[0], t->phase_ms[1] - ph0[1], t->phase_ms[2] - ph0[2] + t->phase_ms[5] - ph0[5] + t->phase_ms[6] - ph0[6],
                      t->phase_ms[3] - ph0[3], t->phase_ms[4] - ph0[4], t->kernel_ms - k0,
                      t->phase_ms[5] - ph0[5], t->phase_ms[6] - ph0[6], t->phase_ms[2] - ph0[2]);
+        std::fprintf(stderr, "[mipx_tree]   probes: read-back %.2f  enqueue %.2f  wait %.2f  results %.2f\n",
+                     t->probe_ms[0] - pr0[0], t->probe_ms[1] - pr0[1], t->probe_ms[2] - pr0[2], t->probe_ms[3] - pr0[3]);
     }
     const double gap = tree_gap(t);
     if (t->unbounded) t->status = 3;
     else if (tree_queue_empty(t) && t->primal == inf) t->status = 2;
     else if (t->primal < inf && gap >= 0 && gap <= mip_gap) t->status = 1;
     else t->status = 4;
-    if (out) return mipx_tree_get_stats(t, out);
+    if (out) mipx_tree_get_stats(t, out);
+    if (hook_stop) return fail(ctx, MIPX_EHOOK, "mipx_tree_solve: stopped by the step hook");
+    return MIPX_OK;
+}
+
+int mipx_tree_set_step_hook(mipx_tree *t, mipx_tree_hook fn, void *user, int every_steps) {
+    if (!t || (fn && every_steps < 1)) return MIPX_EINVAL;
+    t->hook = fn;
+    t->hook_user = user;
+    t->hook_every = fn ? every_steps : 0;
     return MIPX_OK;
 }
 

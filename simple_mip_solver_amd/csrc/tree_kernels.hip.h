@@ -27,6 +27,13 @@ struct ScoreArgs {
     int32_t *mip_feasible;          // batch
     int32_t *n_probe;               // batch
     int32_t *probe_list;            // batch x n_int (ascending position in int_idx)
+    // compact copy of the probe requests for the host (read with the step's single D2H): one
+    // entry per (node, unprobed fractional variable), a node's entries contiguous and ascending;
+    // ask_count may exceed ask_cap (then nothing past the cap is written and the host falls back
+    // to probe_list).  ask == nullptr: not wanted (re-scoring).
+    int32_t *ask_count;
+    int32_t ask_cap;
+    struct Ask { int32_t node, k; double x; } *ask;
 };
 
 __global__ __launch_bounds__(64) void branch_score(ScoreArgs g) {
@@ -79,6 +86,29 @@ __global__ __launch_bounds__(64) void branch_score(ScoreArgs g) {
         g.branch_idx[node] = bvar;
         g.branch_val[node] = bvar < 0 ? 0.0 : x[bvar];
         g.n_probe[node] = nprobe;
+    }
+    if (g.ask != nullptr && nprobe > 0) {  // wave-uniform; rare once the table has filled
+        int off = 0;
+        if (lane == 0) off = atomicAdd(g.ask_count, nprobe);
+        off = __shfl(off, 0);
+        if (off + nprobe <= g.ask_cap) {
+            for (int base = 0; base < g.n_int; base += 64) {
+                const int k = base + lane;
+                bool need_probe = false;
+                double v = 0.0;
+                if (k < g.n_int) {
+                    const int i = g.int_idx[k];
+                    v = x[i];
+                    need_probe = fmin(v - floor(v), ceil(v) - v) > kVarEps && !g.has_entry[i];
+                }
+                const unsigned long long mask = __ballot(need_probe);
+                if (need_probe) {
+                    ScoreArgs::Ask &e = g.ask[off + __popcll(mask & ((1ull << lane) - 1ull))];
+                    e.node = node; e.k = k; e.x = v;
+                }
+                off += __popcll(mask);
+            }
+        }
     }
 }
 

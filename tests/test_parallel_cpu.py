@@ -56,6 +56,28 @@ WORKER = textwrap.dedent('''
     # a second exchange with no new samples changes nothing
     ml2, mr2, ntl2, ntr2 = px.merge(dist, 'cpu', ml, mr, ntl, ntr)
     assert np.array_equal(ml2, ml) and np.array_equal(ntl2, ntl) and np.array_equal(mr2, mr)
+    # the pipelined exchange: what is posted at one call is applied at the next
+    from simple_mip_solver_amd.parallel import PipelinedExchange
+    pe = PipelinedExchange(dist, 'cpu', n, n_counters=2)
+    pe.start(*start)
+    tab = [a.copy() for a in start]
+    def add(tab, side, var, sample):   # running mean, like pseudo_cost.py:97-98
+        c, t = tab[side], tab[2 + side]
+        c[var] = (c[var] * t[var] + sample) / (t[var] + 1); t[var] += 1
+    add(tab, 0, 0, [4.0, 6.0][rank])
+    assert pe.step(INF, [-10.0, -12.5][rank], [1, 10], *tab) is None          # nothing to apply yet
+    add(tab, 0, 1 if rank == 0 else 2, 5.0)                                      # not yet shared
+    gp, gd, cnt, merged = pe.step([INF, -9.0][rank], -9.5, [2, 20], *tab)
+    assert (gp, gd, cnt) == (INF, -12.5, [2, 20]), (gp, gd, cnt)                 # as of the first call
+    # agreed: variable 0 left (2 + 4 + 6) / 3; own unshared sample kept, the other rank's not yet seen
+    assert np.allclose(merged[0], [[4.0, 5.0, 0, 1.0], [4.0, 0, 5.0, 1.0]][rank]), merged[0]
+    assert list(merged[2]) == [[3, 1, 0, 2], [3, 0, 1, 2]][rank]
+    tab = [np.array(a, dtype=b.dtype) for a, b in zip(merged, start)]
+    gp, gd, cnt, merged = pe.drain(-9.0, -9.0, [0, 0], *tab)
+    assert (gp, gd, cnt) == (-9.0, -9.0, [0, 0])
+    assert np.allclose(merged[0], [4.0, 5.0, 5.0, 1.0]) and list(merged[2]) == [3, 1, 1, 2], merged
+    assert np.allclose(merged[1], [4.0, 0, 0, 0]) and list(merged[3]) == [1, 0, 0, 0]
+    assert PipelinedExchange(None, 'cpu', n).step(0, 0, [0], *tab) is None        # single process
     dist.barrier()
     dist.destroy_process_group()
     sys.stdout.write('rank%dok\\n' % rank)  # one write: the two ranks share the pipe

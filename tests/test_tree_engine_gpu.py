@@ -197,3 +197,52 @@ def test_keep_shard_partitions_the_open_nodes(gpu_ctx=None):
     for s in shards:
         st = s.solve(mip_gap=0.0, frontier_batch=8, max_steps=3)
         assert st['dual_bound'] >= st_all['dual_bound'] - 1e-9
+
+
+def test_step_hook_runs_inside_the_step_loop():
+    """mipx_tree_set_step_hook: called every k steps of one solve() with the pipeline running; it
+    may read the tree and install an incumbent bound / pseudo-cost table; a truthy return or an
+    exception stops the solve."""
+    from simple_mip_solver_amd import _ffi
+    ctx = _ffi.default_context()
+    A, b, c, l, u, ints = random_dense_milp_arrays(40, 16, seed=3)
+    prob = _ffi.Problem(ctx, A, b, c)
+    t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=8, pool_capacity=1 << 14)
+    seen = []
+
+    def hook():
+        st = t.stats()
+        seen.append(st['steps'])
+        t.set_pseudo_cost_arrays(*t.pseudo_cost_arrays())   # what a rank does with the merged table
+        return False
+    t.set_step_hook(hook, 3)
+    st = t.solve(mip_gap=0.0, frontier_batch=8, max_steps=10)
+    assert st['status'] == 4 and st['steps'] == 10
+    assert len(seen) == 3 and seen == sorted(seen)          # after 3, 6 and 9 launched steps
+
+    # the hook's search goes the same way as a search without one (the table it installs is its own)
+    t2 = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=8, pool_capacity=1 << 14)
+    st2 = t2.solve(mip_gap=0.0, frontier_batch=8, max_steps=10)
+    assert st2['dual_bound'] == st['dual_bound'] and st2['evaluated_nodes'] == st['evaluated_nodes']
+
+    # an incumbent bound from another rank prunes here: everything is worse than -inf
+    t.set_step_hook(lambda: t.set_primal_bound(-1e30), 1)
+    st = t.solve(mip_gap=0.0, frontier_batch=8, max_steps=50)
+    assert st['open_nodes'] == 0
+
+    # stopping and failing hooks
+    t3 = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=8, pool_capacity=1 << 14)
+    t3.set_step_hook(lambda: True, 2)
+    with pytest.raises(_ffi.MipxError, match='MIPX_EHOOK'):
+        t3.solve(mip_gap=0.0, frontier_batch=8, max_steps=10)
+    assert 2 <= t3.stats()['steps'] <= 3
+
+    def boom():
+        raise RuntimeError('exchange failed')
+    t3.set_step_hook(boom, 1)
+    with pytest.raises(RuntimeError, match='exchange failed'):
+        t3.solve(mip_gap=0.0, frontier_batch=8, max_steps=10)
+    t3.set_step_hook(None)
+    assert t3.solve(mip_gap=0.0, frontier_batch=8, max_steps=2)['status'] == 4
+    with pytest.raises(_ffi.MipxError, match='MIPX_EINVAL'):
+        t3.set_step_hook(lambda: False, 0)
