@@ -77,8 +77,10 @@ def main():
             gpu_index = local_rank % max(1, _ffi.lib().mipx_device_count())
             dist.init_process_group('gloo')
         else:
-            torch.cuda.set_device(local_rank)
-            device = torch.device('cuda', local_rank)
+            # a launcher may narrow the visible devices per rank: index among those this rank sees
+            gpu_index = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(gpu_index)
+            device = torch.device('cuda', gpu_index)
             dist.init_process_group('nccl', device_id=device)
             # first collective now: communicator set-up stays out of the timed region
             warm = torch.zeros(1, dtype=torch.float64, device=device)

@@ -63,6 +63,21 @@ int mipx_ctx_sync(mipx_ctx *ctx);
 int mipx_problem_create(mipx_ctx *ctx, int m, int n, const double *A_rowmajor, const double *b,
                         const double *c, mipx_problem **out);
 void mipx_problem_destroy(mipx_problem *p);
+/* Node LPs with the in-place dive (the frontier engine's throughput option, exposed for parity
+ * tests): where a node LP ends optimal, fractional and with objective < cutoff, and the branching
+ * rule (0 most fractional, base_node.py:544-562; 1 pseudo costs, branch/pseudo_cost.py:118-133,
+ * only when every fractional variable has an entry) picks a basic variable, the workgroup moves
+ * one bound of it (towards the side the rule expects to cost less) and continues the dual simplex
+ * on the tableau it holds: the child LP of base_node.py:592-608 without a reload or a
+ * refactorisation.  HOST buffers.  status, obj, x, vstat_out, iters, npivots have 2 * batch rows:
+ * the nodes, then their children (status -1 where no dive happened); dive_var (-1: none),
+ * dive_dir (0 left: x <= floor, 1 right: x >= ceil), dive_val (the value branched on): batch. */
+int mipx_lp_dive_batch(mipx_problem *p, int batch, const double *l, const double *u,
+                       const int8_t *vstat_in, int max_iter, int rule, const int32_t *int_idx,
+                       int n_int, const double *cost_l, const double *cost_r,
+                       const uint8_t *has_entry, double cutoff, int32_t *status, double *obj,
+                       double *x, int8_t *vstat_out, int32_t *iters, int32_t *npivots,
+                       int32_t *dive_var, int32_t *dive_dir, double *dive_val);
 /*
  * Optional: make warm starts refactor from the tableau of the basis `vstat` (n+m Clp codes, e.g.
  * the root's optimal basis) instead of from the slack basis.  The number of refactorisation pivots

@@ -138,12 +138,34 @@ static void tab_pivot(tab_t *t, int r, int q) {
  *          iters (dual simplex iterations), npivots (refactor + simplex pivots).
  * Any output pointer may be NULL.
  */
-int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const double *c,
-                         const double *l, const double *u, const int8_t *vstat_in, int max_iter,
+/* In-place dive of the frontier engine (lp_kernel.hip.h, LpArgs::dive): when the node LP ends
+ * optimal, fractional and below the cutoff, and the branching rule (K4's: most fractional, or
+ * pseudo costs with every fractional variable initialised) picks a basic variable, one of its
+ * bounds moves (towards the side the rule expects to cost less) and the dual simplex goes on from
+ * the tableau at hand; the child's results go to the second set of outputs.  dive_var = -1: no dive. */
+typedef struct {
+    int32_t rule, n_int;
+    const int32_t *int_idx;
+    const double *cost_l, *cost_r;
+    const uint8_t *has_entry;
+    double cutoff;
+    int32_t *status; double *obj; double *x; int8_t *vstat; int32_t *iters; int32_t *npivots;
+    int32_t *dive_var, *dive_dir; double *dive_val;
+} mipx_dive_t;
+
+static int lp_solve_impl(int m, int n, const double *A, const double *b, const double *c,
+                         const double *l_in, const double *u_in, const int8_t *vstat_in, int max_iter,
                          int32_t *status_out, double *obj_out, double *x_out, double *y_out,
                          double *dj_out, int8_t *vstat_out, int32_t *iters_out,
-                         int32_t *npivots_out) {
+                         int32_t *npivots_out, const mipx_dive_t *dv) {
     if (m < 0 || n <= 0) return -1;
+    /* the dive moves a bound: work on copies */
+    double *l = (double *)malloc(sizeof(double) * (size_t)n);
+    double *u = (double *)malloc(sizeof(double) * (size_t)n);
+    memcpy(l, l_in, sizeof(double) * (size_t)n);
+    memcpy(u, u_in, sizeof(double) * (size_t)n);
+    int pass = 0;
+    if (dv && dv->dive_var) *dv->dive_var = -1;
     tab_t t;
     t.m = m; t.n = n;
     t.T = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1) * n);
@@ -242,9 +264,11 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
 
     /* 3. dual simplex */
     int iters = 0, status = -1;
-    if (g_refactor_only) { status = 3; goto done; }
     int degen = 0; /* consecutive degenerate steps; > m+n switches to Bland's rule (anti-cycling) */
     const int cap = 100 * (m + n) + 1000;
+    if (g_refactor_only) { status = 3; goto done; }
+next_pass:
+    iters = 0; status = -1; degen = 0;
     for (;;) {
         const int bland = degen > m + n;
         /* (a) leaving row */
@@ -352,7 +376,9 @@ done:
         }
     }
     /* 4. outputs */
-    if (x_out || obj_out) {
+    double dive_obj = INFINITY;
+    double *dive_x = NULL;
+    if (x_out || obj_out || (dv && pass == 0)) {
         double *x = (double *)malloc(sizeof(double) * (size_t)n);
         for (int j = 0; j < n; j++) {
             int v = t.nvar[j];
@@ -362,16 +388,15 @@ done:
             int v = t.bvar[i];
             if (v < n) x[v] = fma(bb[i], MIPX_MREPORT, ba[i]);
         }
-        if (obj_out) {
-            if (status == 1) *obj_out = INFINITY;
-            else {
-                for (int j = 0; j < n; j++) buf[j] = c[j] * x[j];
-                for (int j = n; j < n2; j++) buf[j] = 0.0;
-                *obj_out = fold_sum(buf, n2);
-            }
+        if (status == 1) dive_obj = INFINITY;
+        else {
+            for (int j = 0; j < n; j++) buf[j] = c[j] * x[j];
+            for (int j = n; j < n2; j++) buf[j] = 0.0;
+            dive_obj = fold_sum(buf, n2);
         }
+        if (obj_out) *obj_out = dive_obj;
         if (x_out) memcpy(x_out, x, sizeof(double) * (size_t)n);
-        free(x);
+        dive_x = x;
     }
     if (y_out) {
         for (int i = 0; i < m; i++) y_out[i] = 0.0;
@@ -389,9 +414,69 @@ done:
     if (iters_out) *iters_out = iters;
     if (npivots_out) *npivots_out = npiv;
 
+    /* 5. dive: K4's rule on x, then one bound of the chosen (basic) variable moves */
+    if (dv && pass == 0 && !g_refactor_only && status == 0 && dive_obj < dv->cutoff) {
+        const double *x = dive_x;
+        int win = -1, need_probe = 0; double bk = -INFINITY;
+        for (int k = 0; k < dv->n_int; k++) {
+            const int i = dv->int_idx[k];
+            const double v = x[i], fl = floor(v), ce = ceil(v);
+            const double dist = fmin(v - fl, ce - v);
+            if (!(dist > 1e-4)) continue; /* variable_epsilon */
+            double key;
+            if (dv->rule == 0) key = dist;
+            else if (dv->has_entry[i]) key = fmin(dv->cost_r[i] * (ce - v), dv->cost_l[i] * (v - fl));
+            else { need_probe = 1; continue; }
+            if (win < 0 || key > bk) { win = k; bk = key; } /* ties -> earliest in int_idx */
+        }
+        if (win >= 0 && !need_probe) {
+            const int var = dv->int_idx[win];
+            const double v = x[var], fl = floor(v), ce = ceil(v);
+            int dir;
+            if (dv->rule == 0) dir = (v - fl <= ce - v) ? 0 : 1;
+            else dir = (dv->cost_l[var] * (v - fl) <= dv->cost_r[var] * (ce - v)) ? 0 : 1;
+            int basic = 0;
+            for (int i = 0; i < m; i++) if (t.bvar[i] == var) basic = 1;
+            if (basic) {
+                if (dir == 0) u[var] = fl; else l[var] = ce;
+                if (dv->dive_var) *dv->dive_var = var;
+                if (dv->dive_dir) *dv->dive_dir = dir;
+                if (dv->dive_val) *dv->dive_val = v;
+                pass = 1;
+                status_out = dv->status; obj_out = dv->obj; x_out = dv->x; vstat_out = dv->vstat;
+                iters_out = dv->iters; npivots_out = dv->npivots;
+                y_out = NULL; dj_out = NULL;
+                npiv = 0;
+                free(dive_x);
+                goto next_pass;
+            }
+        }
+    }
+    free(dive_x);
+    free(l); free(u);
+
     free(t.T); free(t.beta0); free(t.d); free(t.bvar); free(t.nvar);
     free(atup); free(wantb); free(nb_up); free(ba); free(bb); free(buf); free(va); free(vb);
     return 0;
+}
+
+int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const double *c,
+                         const double *l, const double *u, const int8_t *vstat_in, int max_iter,
+                         int32_t *status_out, double *obj_out, double *x_out, double *y_out,
+                         double *dj_out, int8_t *vstat_out, int32_t *iters_out,
+                         int32_t *npivots_out) {
+    return lp_solve_impl(m, n, A, b, c, l, u, vstat_in, max_iter, status_out, obj_out, x_out, y_out, dj_out,
+                         vstat_out, iters_out, npivots_out, NULL);
+}
+
+/* one node LP with the in-place dive (outputs of the child through dv) */
+int mipx_oracle_lp_solve_dive(int m, int n, const double *A, const double *b, const double *c,
+                              const double *l, const double *u, const int8_t *vstat_in, int max_iter,
+                              int32_t *status_out, double *obj_out, double *x_out,
+                              int8_t *vstat_out, int32_t *iters_out, int32_t *npivots_out,
+                              const mipx_dive_t *dv) {
+    return lp_solve_impl(m, n, A, b, c, l, u, vstat_in, max_iter, status_out, obj_out, x_out, NULL, NULL,
+                         vstat_out, iters_out, npivots_out, dv);
 }
 
 /* batch of node LPs sharing (A,b,c): l,u are batch x n, vstat batch x (n+m) (or NULL) */

@@ -70,6 +70,52 @@ def lp_solve_batch(A, b, c, l, u, vstat=None, max_iter=0):
     return dict(status=status, obj=obj, x=x, y=y, vstat=vout, iters=iters, npivots=npiv)
 
 
+class _Dive(C.Structure):
+    _fields_ = [('rule', C.c_int32), ('n_int', C.c_int32), ('int_idx', _i32p), ('cost_l', _dp),
+                ('cost_r', _dp), ('has_entry', C.POINTER(C.c_uint8)), ('cutoff', C.c_double),
+                ('status', _i32p), ('obj', _dp), ('x', _dp), ('vstat', _i8p), ('iters', _i32p),
+                ('npivots', _i32p), ('dive_var', _i32p), ('dive_dir', _i32p), ('dive_val', _dp)]
+
+
+def lp_solve_dive_batch(A, b, c, l, u, vstat, rule, int_idx, cost_l, cost_r, has_entry, cutoff,
+                        max_iter=0):
+    """Node LPs with the in-place dive (LpArgs::dive of the GPU kernel): every array of the result
+    has 2 * batch rows -- the nodes, then their dive children (status -1 where none was solved) --
+    plus dive_var (-1: no dive), dive_dir, dive_val per node."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    m, n = A.shape
+    b = np.ascontiguousarray(b, dtype=np.float64).reshape(m)
+    c = np.ascontiguousarray(c, dtype=np.float64).reshape(n)
+    l = np.ascontiguousarray(l, dtype=np.float64).reshape(-1, n)
+    u = np.ascontiguousarray(u, dtype=np.float64).reshape(-1, n)
+    B = l.shape[0]
+    if vstat is not None:
+        vstat = np.ascontiguousarray(vstat, dtype=np.int8).reshape(B, n + m)
+    ii = np.ascontiguousarray(int_idx, np.int32)
+    cl = np.ascontiguousarray(cost_l, np.float64); cr = np.ascontiguousarray(cost_r, np.float64)
+    he = np.ascontiguousarray(has_entry, np.uint8)
+    status = np.full(2 * B, -1, np.int32); obj = np.zeros(2 * B); x = np.zeros((2 * B, n))
+    vout = np.zeros((2 * B, n + m), np.int8); iters = np.zeros(2 * B, np.int32)
+    npiv = np.zeros(2 * B, np.int32)
+    dvar = np.full(B, -1, np.int32); ddir = np.zeros(B, np.int32); dval = np.zeros(B)
+    f = lib().mipx_oracle_lp_solve_dive
+    f.restype = C.c_int
+    at = lambda a, k, t: C.cast(a[k:].ctypes.data, t)
+    for k in range(B):
+        dv = _Dive(int(rule), len(ii), _p(ii, _i32p), _p(cl, _dp), _p(cr, _dp),
+                   he.ctypes.data_as(C.POINTER(C.c_uint8)), float(cutoff),
+                   at(status, B + k, _i32p), at(obj, B + k, _dp), at(x, B + k, _dp),
+                   at(vout, B + k, _i8p), at(iters, B + k, _i32p), at(npiv, B + k, _i32p),
+                   at(dvar, k, _i32p), at(ddir, k, _i32p), at(dval, k, _dp))
+        rc = f(C.c_int(m), C.c_int(n), _p(A, _dp), _p(b, _dp), _p(c, _dp), at(l, k, _dp), at(u, k, _dp),
+               None if vstat is None else at(vstat, k, _i8p), C.c_int(int(max_iter)),
+               at(status, k, _i32p), at(obj, k, _dp), at(x, k, _dp), at(vout, k, _i8p),
+               at(iters, k, _i32p), at(npiv, k, _i32p), C.byref(dv))
+        assert rc == 0, f'oracle lp_solve_dive failed rc={rc}'
+    return dict(status=status, obj=obj, x=x, vstat=vout, iters=iters, npivots=npiv, dive_var=dvar,
+                dive_dir=ddir, dive_val=dval)
+
+
 def lp_solve(A, b, c, l, u, vstat=None, max_iter=0):
     r = lp_solve_batch(A, b, c, np.asarray(l, float)[None], np.asarray(u, float)[None],
                        None if vstat is None else np.asarray(vstat, np.int8)[None], max_iter)

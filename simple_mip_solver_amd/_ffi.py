@@ -25,7 +25,7 @@ SYMBOLS = [
     'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
     'mipx_tree_solution', 'mipx_tree_set_primal_bound', 'mipx_tree_pseudo_costs', 'mipx_tree_set_pseudo_costs',
     'mipx_tree_set_trace', 'mipx_tree_trace', 'mipx_tree_peek_open', 'mipx_tree_keep_shard',
-    'mipx_tree_set_step_hook',
+    'mipx_tree_set_step_hook', 'mipx_lp_dive_batch',
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -263,6 +263,35 @@ class Problem:
                                        _ptr(iters), _ptr(npiv))
         self.ctx.check(rc, 'mipx_lp_solve_batch')
         return dict(status=status, obj=obj, x=x, y=y, vstat=vout, iters=iters, npivots=npiv)
+
+    def dive_batch(self, l, u, vstat, rule, integer_indices, cost_l=None, cost_r=None, has_entry=None,
+                   cutoff=float('inf'), max_iter=0):
+        """Node LPs with the in-place dive (mipx_lp_dive_batch); arrays of 2 * batch rows (nodes,
+        then dive children, status -1 where none) plus dive_var / dive_dir / dive_val per node."""
+        n, m = self.n, self.m
+        l = np.ascontiguousarray(l, dtype=np.float64).reshape(-1, n)
+        B = l.shape[0]
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(B, n)
+        if vstat is not None:
+            vstat = np.ascontiguousarray(vstat, dtype=np.int8).reshape(B, n + m)
+        ii = np.ascontiguousarray(integer_indices, dtype=np.int32)
+        cl = None if cost_l is None else np.ascontiguousarray(cost_l, np.float64)
+        cr = None if cost_r is None else np.ascontiguousarray(cost_r, np.float64)
+        he = None if has_entry is None else np.ascontiguousarray(has_entry, np.uint8)
+        status = np.zeros(2 * B, np.int32); obj = np.zeros(2 * B); x = np.zeros((2 * B, n))
+        vout = np.zeros((2 * B, n + m), np.int8); iters = np.zeros(2 * B, np.int32)
+        npiv = np.zeros(2 * B, np.int32)
+        dvar = np.zeros(B, np.int32); ddir = np.zeros(B, np.int32); dval = np.zeros(B)
+        L = lib()
+        L.mipx_lp_dive_batch.argtypes = [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int,
+                                         _vp, _vp, _vp, C.c_double] + [_vp] * 9
+        rc = L.mipx_lp_dive_batch(self._h, B, _ptr(l), _ptr(u), _ptr(vstat), int(max_iter), int(rule),
+                                  _ptr(ii), len(ii), _ptr(cl), _ptr(cr), _ptr(he), float(cutoff),
+                                  _ptr(status), _ptr(obj), _ptr(x), _ptr(vout), _ptr(iters), _ptr(npiv),
+                                  _ptr(dvar), _ptr(ddir), _ptr(dval))
+        self.ctx.check(rc, 'mipx_lp_dive_batch')
+        return dict(status=status, obj=obj, x=x, vstat=vout, iters=iters, npivots=npiv, dive_var=dvar,
+                    dive_dir=ddir, dive_val=dval)
 
     def gomory_batch(self, l, u, vstat, x, integer_indices, max_term=1e3):
         """GMI cuts + safe rounding for solved nodes; list (one per node) of dicts with

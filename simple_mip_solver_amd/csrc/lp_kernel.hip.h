@@ -66,7 +66,24 @@ struct LpArgs {
     int dbg_all;        // 0: node 0 only; 1: every node k at offsets k*m*n, k*(n+3m), k*(2n+m)
     unsigned long long *prof = nullptr;  // MIPX_KPROF builds only: per-section cycle totals of one wave
     int prof_wave = 0;
+    // optional dive (frontier engine): when the node LP ends optimal, fractional and below the
+    // cutoff, and the branching rule can decide without strong-branching probes, the workgroup
+    // branches in place -- one bound of the (basic) branching variable moves -- and goes on with the
+    // dual simplex on the tableau it holds in registers: the child costs its few iterations, not a
+    // tableau load and a refactorisation.  The child's outputs go to position node + dive_off of
+    // the same output arrays; dive_var[node] (preset to -1 by the caller) says whether it happened.
+    int dive = 0, dive_off = 0;
+    int rule = 0;                   // 0 most fractional, 1 pseudo cost (K4's rules)
+    int n_int = 0;
+    const int32_t *int_idx = nullptr;
+    const double *cost_l = nullptr, *cost_r = nullptr;
+    const uint8_t *has_entry = nullptr;
+    double dive_cutoff = 0.0;       // dive only below this objective (the incumbent at launch)
+    int32_t *dive_var = nullptr, *dive_dir = nullptr;
+    double *dive_val = nullptr;
 };
+
+constexpr double kVarEps = 1e-4;  // utils/tolerance.py:2 variable_epsilon
 
 #ifdef MIPX_KPROF
 #define KPROF_MARK(k)                                  \
@@ -323,6 +340,7 @@ struct Smem {
     int wlist[NP];      // columns of the variables the warm start wants basic, ascending variable
     int nw;
     int nfake0;
+    int dive_code;      // branching variable of the in-place dive, -1: none
     int seq;            // pivot column parts published so far (one count per tableau wave and column)
     int pos[NP + MP];   // column of each variable in the starting tableau, -1 if basic
     int8_t wantb[NP + MP];
@@ -561,7 +579,7 @@ _Pragma("unroll")                                                               
 // tableau waves (whole rows of T in registers, rank-1 updates).  They meet at three barriers per
 // simplex iteration (row chosen / row published / column chosen) and two per refactorisation
 // pivot; the pivot column goes to the control wave through s.alpha and the s.seq counter.
-template <int NW, int R, int C, int MP>
+template <int NW, int R, int C, int MP, bool DIVE = false>
 __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
     constexpr int NT = 64 * (NW + 1);
     constexpr int NG = 4 * NW;          // row groups of the workgroup (4 per tableau wave)
@@ -831,9 +849,10 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
         }
     }
 
-    if (!(vin && g.refactor_only)) {
+    const bool solve = !(vin && g.refactor_only);
+    int nfake = 0;  // nonbasic columns at the symbolic bound M (control wave)
+    if (solve) {
         // ---- 2. nonbasic sides and values (control wave), then the basic values ---------------
-        int nfake = 0;  // nonbasic columns at the symbolic bound M (control wave)
         if (ctl) {
 #pragma unroll
             for (int kk = 0; kk < PJ; kk++) {
@@ -932,7 +951,17 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
         }
         __syncthreads();
         KPROF_MARK(7);
+    }
 
+    // pass 0: the node; pass 1: its child after an in-place dive (g.dive)
+    int pass = 0;
+    asm volatile("" : "+s"(pass));  // opaque: keeps the compiler from peeling the first pass (two copies of the sweep)
+    size_t onode = (size_t)node;
+    int dvar = -1, ddir = 0;     // control wave: the dive's branching variable, direction,
+    double dbound = 0.0;         //   and the bound that moves (floor / ceil of its value)
+#pragma clang loop unroll(disable)
+    for (;;) {
+    if (solve) {
         // ---- 3. dual simplex ------------------------------------------------------------------
         // Control wave: leaving row r | A | (row r arrives) | B | ratio test: column q | C | reduced
         // costs, wait for column q, basic values, next leaving row | A ...
@@ -946,11 +975,24 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
             double sel_b0 = 0.0, sel_ba = 0.0, sel_bb = 0.0;  // border values of row r
             int sel_win = 0, sel_lvmeta = 0;
             double sel_la = 0.0;
+            if (pass == 0) {
 #pragma unroll
-            for (int kk = 0; kk < PI; kk++) {
-                const int i = lane + 64 * kk;
-                rBa[kk] = i < MP ? rB0[kk] - s.ba[i < MP ? i : 0] : 0.0;
-                rBb[kk] = i < MP ? s.bb[i < MP ? i : 0] : 0.0;
+                for (int kk = 0; kk < PI; kk++) {
+                    const int i = lane + 64 * kk;
+                    rBa[kk] = i < MP ? rB0[kk] - s.ba[i < MP ? i : 0] : 0.0;
+                    rBb[kk] = i < MP ? s.bb[i < MP ? i : 0] : 0.0;
+                }
+            } else {  // the dive: one bound of the (basic) branching variable moves
+#pragma unroll
+                for (int kk = 0; kk < PI; kk++) {
+                    const bool hit = (rM[kk] >> 2) == dvar;
+                    rUp[kk] = (hit && ddir == 0) ? dbound : rUp[kk];
+                    rLo[kk] = (hit && ddir != 0) ? dbound : rLo[kk];
+                }
+                if (lane == 0) {
+                    if (ddir == 0) s.up[dvar] = dbound;
+                    else s.lo[dvar] = dbound;
+                }
             }
             MIPX_LEAVE_SELECT();
             __syncthreads();  // A
@@ -1062,6 +1104,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
                 KPROF_MARK(0);
             }
             (void)nfk0;
+            nfake = nfk;
         } else {
             __syncthreads();  // A
             for (;;) {
@@ -1093,6 +1136,13 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
         status = 3;
     }
 
+    // Sections 4 and 5 sit inside the pass loop: without the opaque copies below the compiler hoists
+    // their loop-invariant indices, predicates and addresses above the whole solve (290 spilled
+    // SGPRs, 164 spilled VGPRs).
+    int o_tid = tid, o_lane = lane, o_n = n, o_m = m;
+    asm volatile("" : "+v"(o_tid), "+v"(o_lane), "+s"(o_n), "+s"(o_m));
+    {
+    const int tid = o_tid, lane = o_lane, n = o_n, m = o_m, nv = o_n + o_m;
     // ---- 4. outputs ---------------------------------------------------------------------------
 #ifdef MIPX_KPROF
     KPROF_MARK(6);
@@ -1136,15 +1186,15 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
     for (int j = n + tid; j < NP; j += NT) s.key[j] = 0.0;
     __syncthreads();
     if (g.x)
-        for (int j = tid; j < n; j += NT) g.x[(size_t)node * n + j] = s.key[j];
+        for (int j = tid; j < n; j += NT) g.x[onode * n + j] = s.key[j];
     if (g.y) {
-        for (int i = tid; i < m; i += NT) g.y[(size_t)node * m + i] = 0.0;
+        for (int i = tid; i < m; i += NT) g.y[onode * m + i] = 0.0;
         __syncthreads();
         for (int j = tid; j < n; j += NT)
-            if (s.nvar[j] >= n) g.y[(size_t)node * m + (s.nvar[j] - n)] = s.d[j];
+            if (s.nvar[j] >= n) g.y[onode * m + (s.nvar[j] - n)] = s.d[j];
     }
     if (g.vstat_out) {
-        int8_t *vo = g.vstat_out + (size_t)node * nv;
+        int8_t *vo = g.vstat_out + onode * nv;
         for (int i = tid; i < m; i += NT) vo[s.bvar[i]] = 1;
         for (int j = tid; j < n; j += NT) vo[s.nvar[j]] = s.side[j] ? 2 : 3;
     }
@@ -1173,6 +1223,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
             didx[n + i] = s.bvar[i];
         }
     }
+    double objv = 0.0;
     if (tid < 64) {
         // obj = fold-in-half sum of c_j x_j over the padded power-of-two length
         constexpr int PER = NP / 64;
@@ -1191,13 +1242,73 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
 #pragma unroll
         for (int h = 32; h >= 1; h >>= 1) sum = sum + __shfl_down(sum, h, 64);
         if (tid == 0) {
-            if (g.obj) g.obj[node] = status == 1 ? INF : sum;
-            if (g.status) g.status[node] = status;
-            if (g.iters) g.iters[node] = iters;
-            if (g.npivots) g.npivots[node] = npiv;
+            if (g.obj) g.obj[onode] = status == 1 ? INF : sum;
+            if (g.status) g.status[onode] = status;
+            if (g.iters) g.iters[onode] = iters;
+            if (g.npivots) g.npivots[onode] = npiv;
         }
+        objv = uniform_f64(sum);
     }
     __syncthreads();
+    if (!DIVE || !g.dive || pass != 0 || !solve) break;  // (DIVE = false: the pass loop folds away)
+
+    // ---- 5. dive: K4's branching rule on the solution in s.key, by the control wave -----------
+    if (ctl) {
+        int code = -1;
+        if (status == 0 && objv < g.dive_cutoff) {
+            double bk = -INF;
+            int bp = kNoCand, nprobe = 0;
+            for (int base = 0; base < g.n_int; base += 64) {
+                const int k = base + lane;
+                bool need_probe = false;
+                if (k < g.n_int) {
+                    const int i = g.int_idx[k];
+                    const double v = s.key[i];
+                    const double fl = floor(v), ce = ceil(v);
+                    const double dist = fmin(v - fl, ce - v);
+                    const bool frac = dist > kVarEps;
+                    if (g.rule == 0) {
+                        keep(bk, bp, dist, k, frac);
+                    } else if (frac) {
+                        if (g.has_entry[i]) keep(bk, bp, fmin(g.cost_r[i] * (ce - v), g.cost_l[i] * (v - fl)), k, true);
+                        else need_probe = true;
+                    }
+                }
+                nprobe += __popcll(__ballot(need_probe));
+            }
+            double km;
+            const int win = wave_argmax(bk, bp, km);
+            if (win != kNoCand && nprobe == 0) {
+                dvar = __builtin_amdgcn_readfirstlane(g.int_idx[win]);
+                const double v = uniform_f64(s.key[dvar]);
+                const double fl = floor(v), ce = ceil(v);
+                // towards the side the rule expects to cost less (most fractional: the nearer one)
+                if (g.rule == 0) ddir = (v - fl <= ce - v) ? 0 : 1;
+                else ddir = (uniform_f64(g.cost_l[dvar]) * (v - fl) <= uniform_f64(g.cost_r[dvar]) * (ce - v)) ? 0 : 1;
+                dbound = ddir == 0 ? fl : ce;
+                bool mine = false;  // a bound change in place needs the variable basic
+#pragma unroll
+                for (int kk = 0; kk < PI; kk++) mine |= (lane + 64 * kk < m) && (rM[kk] >> 2) == dvar;
+                if (__ballot(mine) != 0ull) {
+                    code = dvar;
+                    if (lane == 0) {
+                        g.dive_var[node] = dvar;
+                        g.dive_dir[node] = ddir;
+                        g.dive_val[node] = v;
+                    }
+                }
+            }
+        }
+        if (lane == 0) s.dive_code = code;
+    }
+    __syncthreads();
+    }
+    if (__builtin_amdgcn_readfirstlane(s.dive_code) < 0) break;
+    pass = 1;
+    onode = (size_t)node + (size_t)g.dive_off;
+    iters = 0;
+    npiv = 0;
+    }
 }
 
 #undef MIPX_PUBLISH_COL

@@ -13,8 +13,6 @@
 
 namespace mipx {
 
-constexpr double kVarEps = 1e-4;  // utils/tolerance.py:2 variable_epsilon
-
 struct ScoreArgs {
     int n, n_int, batch, rule;      // rule 0: most fractional, 1: pseudo cost
     const int32_t *int_idx;         // n_int

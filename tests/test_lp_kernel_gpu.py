@@ -298,3 +298,72 @@ def test_tile_boundaries_and_edge_cases(n, m, gpu_ctx, oracle):
         gg = p.solve_batch(L, U, np.repeat(g0['vstat'], len(L), 0))
         oo = oracle.lp_solve_batch(A, b, c, L, U, np.repeat(g0['vstat'], len(L), 0))
         assert_same(gg, oo, f'cousins {n}x{m}')
+
+
+def _assert_same_dive(g, o, what=''):
+    for key in ('status', 'iters', 'npivots', 'dive_var', 'dive_dir'):
+        assert np.array_equal(g[key], o[key]), f'{what} {key}'
+    assert np.array_equal(g['dive_val'][g['dive_var'] >= 0], o['dive_val'][o['dive_var'] >= 0]), f'{what} dive_val'
+    done = g['status'] >= 0
+    assert np.array_equal(g['vstat'][done], o['vstat'][done]), f'{what} basis'
+    fin = (g['status'] == 0) | (g['status'] == 3)
+    assert np.array_equal(g['x'][fin], o['x'][fin]), f'{what} x'
+    ok = done & (g['status'] != 1)
+    assert np.array_equal(g['obj'][ok], o['obj'][ok]), f'{what} obj'
+    assert np.all(np.isposinf(g['obj'][g['status'] == 1]))
+
+
+@pytest.mark.parametrize('n,m,seed', [(24, 10, 1), (64, 32, 0), (100, 40, 2), (256, 128, 0)])
+@pytest.mark.parametrize('rule', [0, 1])
+def test_in_place_dive_matches_oracle(n, m, seed, rule, gpu_ctx, oracle):
+    """The dive (child LP continued on the register tableau after a bound of the branching
+    variable moved) is bit-identical to the oracle's restatement of it: same branching decision,
+    same pivots, same child solution; and the child is the LP an ordinary warm-started solve of
+    the moved bounds reaches (same optimum within rounding)."""
+    A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=seed)
+    p = _ffi.Problem(gpu_ctx, A, b, c)
+    root = p.solve_batch(l[None], u[None])
+    L, U, V = _children(A, b, c, l, u, root, 8)
+    rng = np.random.default_rng(seed)
+    cost_l, cost_r = rng.uniform(0.5, 4.0, n), rng.uniform(0.5, 4.0, n)
+    has = np.ones(n, np.uint8)
+    for anchored in (False, True):
+        if anchored:
+            p.set_anchor(root['vstat'][0])
+            cm = oracle.anchored(oracle.make_anchor(A, b, c, root['vstat'][0]))
+        else:
+            import contextlib
+            cm = contextlib.nullcontext()
+        g = p.dive_batch(L, U, V, rule, ints, cost_l, cost_r, has)
+        with cm:
+            o = oracle.lp_solve_dive_batch(A, b, c, L, U, V, rule, ints, cost_l, cost_r, has, np.inf)
+        _assert_same_dive(g, o, f'dive rule {rule} anchored {anchored}')
+        B = len(L)
+        dived = np.where(g['dive_var'] >= 0)[0]
+        assert len(dived) >= 1 and np.all(g['status'][B:][g['dive_var'] < 0] == -1)
+        # the parents are what the plain kernel computes
+        plain = p.solve_batch(L, U, V)
+        for key in ('status', 'obj', 'x', 'vstat', 'iters', 'npivots'):
+            assert np.array_equal(g[key][:B], plain[key]), key
+        # each child = a warm-started solve of the parent's bounds with the dive's bound moved
+        L2, U2 = L[dived].copy(), U[dived].copy()
+        for r, k in enumerate(dived):
+            v = g['dive_var'][k]
+            assert v in ints and abs(g['dive_val'][k] - plain['x'][k][v]) == 0
+            if g['dive_dir'][k] == 0:
+                U2[r, v] = np.floor(g['dive_val'][k])
+            else:
+                L2[r, v] = np.ceil(g['dive_val'][k])
+        again = p.solve_batch(L2, U2, plain['vstat'][dived])
+        assert np.array_equal(again['status'], g['status'][B:][dived])
+        fin = again['status'] == 0
+        assert np.allclose(again['obj'][fin], g['obj'][B:][dived][fin], rtol=0, atol=1e-7)
+        # and it costs its simplex iterations only: no refactorisation pivots
+        assert np.array_equal(g['npivots'][B:][dived], g['iters'][B:][dived])
+    p.set_anchor(None)
+    # a cutoff below every objective, or a missing pseudo-cost entry, switches the dive off
+    g = p.dive_batch(L, U, V, rule, ints, cost_l, cost_r, has, cutoff=-1e30)
+    assert np.all(g['dive_var'] == -1) and np.all(g['status'][len(L):] == -1)
+    if rule == 1:
+        g = p.dive_batch(L, U, V, 1, ints, cost_l, cost_r, np.zeros(n, np.uint8))
+        assert np.all(g['dive_var'] == -1)
