@@ -38,12 +38,14 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 
 F64_VECTOR_PEAK_TFLOPS = 78.6
 
 
-def algorithmic_bytes(m, n, lps, pivots):
+def algorithmic_bytes(m, n, lps, pivots, dives=0):
     """SURVEY.md section 8(d), dense-tableau model, f64: per LP load A,b,c,l,u + store x, obj,
-    status, basis; per pivot one read + one write of the bordered tableau."""
+    status, basis; per pivot one read + one write of the bordered tableau.  A dive child continues
+    on its parent's tableau: it is charged its outputs and pivots, not a load."""
     per_pivot = 2 * 8 * (m + 1) * (n + m + 1)
-    per_lp = 8 * (m * n + m + 3 * n) + 8 * (n + 2) + (n + m)
-    return lps * per_lp + pivots * per_pivot
+    load = 8 * (m * n + m + 3 * n)
+    store = 8 * (n + 2) + (n + m)
+    return (lps - dives) * load + lps * store + pivots * per_pivot
 
 
 def main():
@@ -58,6 +60,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--cpu-threads', type=int, default=16, help='threads of the CPU baseline (over nodes)')
     ap.add_argument('--exchange-every', type=int, default=5, help='steps between all-reduces (N > 1)')
+    ap.add_argument('--dive', type=int, default=1, choices=[0, 1],
+                    help='1: one-level plunge on the register tableau (mipx_tree_set_dive)')
     ap.add_argument('--no-anchor', action='store_true',
                     help='refactor every node from the slack basis instead of the root tableau')
     args = ap.parse_args()
@@ -93,10 +97,12 @@ def main():
     prob = _ffi.Problem(ctx, A, b, c)
     tree = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', search_rule='best first',
                      strong_branch_iters=5, max_batch=B,
-                     pool_capacity=2 * B * (args.steps + args.warmup + 4) + 4 * B * world)
+                     pool_capacity=(2 + 2 * args.dive) * B * (args.steps + args.warmup + 4) + 4 * B * world)
 
     if not args.no_anchor:
         tree.set_anchor_mode(True)  # warm starts refactor from the root's optimal tableau
+    if args.dive:
+        tree.set_dive(True)
 
     # ---- untimed: replicated ramp-up, then sharding ------------------------------------------
     st = tree.stats()
@@ -135,10 +141,18 @@ def main():
         deadline = time.perf_counter() + args.cpu_seconds
         done_chunks = []
 
+        pc_tab = tree.pseudo_cost_arrays()
+        pc_has = ((pc_tab[2] > 0) | (pc_tab[3] > 0)).astype(np.uint8)
+        cutoff = tree.stats()['primal_bound']
+
         def work(ci):  # ctypes releases the GIL inside the C oracle: the threads run in parallel
             if time.perf_counter() > deadline:
                 return 0
             e0 = min((ci + 1) * chunk, len(L))
+            if args.dive:  # like the GPU path: node + one child continued on the node's tableau
+                r = O.lp_solve_dive_batch(A, b, c, L[ci * chunk:e0], U[ci * chunk:e0], V[ci * chunk:e0], 1,
+                                          ints, pc_tab[0], pc_tab[1], pc_has, cutoff)
+                return e0 - ci * chunk + int((r['dive_var'] >= 0).sum())
             O.lp_solve_batch(A, b, c, L[ci * chunk:e0], U[ci * chunk:e0], V[ci * chunk:e0])
             return e0 - ci * chunk
 
@@ -164,7 +178,7 @@ def main():
         except Exception:
             pass
         cpu = {'value': done / t_cpu, 'unit': 'node LP-relaxations/s', 'cores': threads, 'kind': 'port',
-               'sample': f'{done} node LPs = {passes} pass(es) over {len(L)} open nodes of the same tree (the LPs the GPU solves next: bounds + '
+               'sample': f'{done} node LPs = {passes} pass(es) over {len(L)} open nodes of the same tree{" and their dive children" if args.dive else ""} (the LPs the GPU solves next: bounds + '
                          f'warm-start bases read back from the device pool), oracle/libmipx_oracle.so '
                          f'({"anchored at the root tableau like the GPU path" if not args.no_anchor else "slack-basis refactorisation"}), '
                          f'{threads} threads over nodes, {t_cpu:.1f} s wall; host: {os.cpu_count()} logical '
@@ -216,16 +230,19 @@ def main():
         A2, b2, c2, l2, u2, ints2 = random_dense_milp_arrays(80, 40, seed=0)
         p2 = _ffi.Problem(ctx, A2, b2, c2)
         t2 = _ffi.Tree(p2, ints2, l2, u2, branch_rule='pseudo cost', max_batch=4096, pool_capacity=1 << 21)
+        if args.dive:
+            t2.set_dive(True)
         tt = time.perf_counter()
         s2 = t2.solve(mip_gap=1e-4, frontier_batch=4096, max_seconds=30.0)
-        tto = {'instance': '80 vars x 40 rows, seed 0, same generator, PseudoCostBranchNode best-first',
+        tto = {'instance': '80 vars x 40 rows, seed 0, same generator, PseudoCostBranchNode best-first'
+                           + (' + one-level dive' if args.dive else ''),
                'seconds': time.perf_counter() - tt,
                'status': _ffi.TREE_STATUS[s2['status']], 'objective': s2['primal_bound'],
                'nodes': s2['evaluated_nodes']}
         t2.close(); p2.close()
 
     d = {k: after[k] - before[k] for k in ('lp_solved', 'probes_solved', 'pivots', 'evaluated_nodes',
-                                           'kernel_ms', 'steps')}
+                                           'kernel_ms', 'steps', 'dives')}
     gp, gd, sums, _ = exchange(dist, device, after['primal_bound'], after['dual_bound'],
                                [d['lp_solved'], d['probes_solved'], d['pivots'], after['open_nodes'],
                                 after['evaluated_nodes']])
@@ -238,7 +255,7 @@ def main():
     if rank == 0:
         assert d['steps'] == args.steps, 'frontier ran dry inside the timed region'
         launch_s = d['kernel_ms'] * 1e-3 / args.steps
-        achieved = algorithmic_bytes(m, n, d['lp_solved'], d['pivots']) / args.steps / launch_s / 1e9
+        achieved = algorithmic_bytes(m, n, d['lp_solved'], d['pivots'], d['dives']) / args.steps / launch_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
         if os.path.exists(pmc):
@@ -256,9 +273,11 @@ def main():
             'config': {
                 'workload': f'C3: {n} vars x {m} rows random dense MILP (BASELINE.md sec. 4, seed '
                             f'{args.seed}), PseudoCostBranchNode, best-first, strong_branch_iters=5, '
-                            f'gomory_cuts=False, native frontier engine, {B} open nodes per step per GPU',
+                            f'gomory_cuts=False, native frontier engine, {B} open nodes per step per GPU'
+                            + (' + one-level dive (each node and, where the rule needs no probes, one child on the same register tableau)' if args.dive else ''),
                 'frontier_batch_per_gpu': B, 'kernel': _ffi.kernel_name(m, n),
-                'anchored_refactorisation': not args.no_anchor,
+                'anchored_refactorisation': not args.no_anchor, 'dive': bool(args.dive),
+                'dive_children_per_step': d['dives'] / args.steps,
                 'mean_pivots_per_lp': d['pivots'] / max(1, d['lp_solved']),
                 'sb_probes_per_s': sums[1] / elapsed,
                 'nodes_evaluated_total': sums[4], 'open_nodes_total': sums[3],

@@ -211,6 +211,7 @@ typedef struct mipx_tree_stats {
     int32_t status;           /* 0 unsolved, 1 optimal, 2 infeasible, 3 unbounded,
                                  4 stopped on iterations or time */
     int32_t has_solution;
+    int64_t dives;            /* of lp_solved / evaluated_nodes: children solved in place by the dive */
 } mipx_tree_stats;
 
 /*
@@ -239,6 +240,12 @@ int mipx_tree_pseudo_costs(mipx_tree *t, double *cost_l, double *cost_r, int32_t
  * (PseudoCostBranchNode.pseudo_costs shared through _kwargs, branch/pseudo_cost.py:38-43). */
 int mipx_tree_set_pseudo_costs(mipx_tree *t, const double *cost_l, const double *cost_r,
                                const int32_t *times_l, const int32_t *times_r);
+/* Throughput option for frontier batches > 1 (register-tile shapes): the workgroup that solved a
+ * node branches in place when the rule can decide without probes (see mipx_lp_dive_batch) and
+ * solves one child on the tableau it holds; that child is evaluated in the same step (its sibling
+ * is queued as usual).  A best-first search with a one-level plunge: same optimum, different node
+ * order.  Not available with max_batch = 1 (the reference's exact order). */
+int mipx_tree_set_dive(mipx_tree *t, int on);
 /* Step hook: `fn(user)` is called on the calling thread every `every_steps` frontier steps of
  * mipx_tree_solve, after the next step's kernels are queued and before the host waits for the
  * current one -- the slot in which a multi-GPU rank runs its incumbent / bound / pseudo-cost

@@ -479,6 +479,36 @@ int mipx_oracle_lp_solve_dive(int m, int n, const double *A, const double *b, co
                          vstat_out, iters_out, npivots_out, dv);
 }
 
+/* batch with the dive: every output array has 2 * batch rows (the nodes, then their dive children;
+ * the caller presets status[batch..] = -1 and dive_var[] = -1) */
+int mipx_oracle_lp_solve_dive_batch(int m, int n, const double *A, const double *b, const double *c,
+                                    int batch, const double *l, const double *u,
+                                    const int8_t *vstat_in, int max_iter, int rule, int n_int,
+                                    const int32_t *int_idx, const double *cost_l, const double *cost_r,
+                                    const uint8_t *has_entry, double cutoff, int32_t *status,
+                                    double *obj, double *x, int8_t *vstat_out, int32_t *iters,
+                                    int32_t *npivots, int32_t *dive_var, int32_t *dive_dir,
+                                    double *dive_val) {
+    const size_t nv = (size_t)n + m;
+    for (int k = 0; k < batch; k++) {
+        const size_t ck = (size_t)batch + k;
+        mipx_dive_t dv;
+        dv.rule = rule; dv.n_int = n_int; dv.int_idx = int_idx;
+        dv.cost_l = cost_l; dv.cost_r = cost_r; dv.has_entry = has_entry; dv.cutoff = cutoff;
+        dv.status = status + ck; dv.obj = obj ? obj + ck : NULL; dv.x = x ? x + ck * n : NULL;
+        dv.vstat = vstat_out ? vstat_out + ck * nv : NULL;
+        dv.iters = iters ? iters + ck : NULL; dv.npivots = npivots ? npivots + ck : NULL;
+        dv.dive_var = dive_var + k; dv.dive_dir = dive_dir + k; dv.dive_val = dive_val + k;
+        int rc = lp_solve_impl(m, n, A, b, c, l + (size_t)k * n, u + (size_t)k * n,
+                               vstat_in ? vstat_in + (size_t)k * nv : NULL, max_iter, status + k,
+                               obj ? obj + k : NULL, x ? x + (size_t)k * n : NULL, NULL, NULL,
+                               vstat_out ? vstat_out + (size_t)k * nv : NULL, iters ? iters + k : NULL,
+                               npivots ? npivots + k : NULL, &dv);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 /* batch of node LPs sharing (A,b,c): l,u are batch x n, vstat batch x (n+m) (or NULL) */
 int mipx_oracle_lp_solve_batch(int m, int n, const double *A, const double *b, const double *c,
                                int batch, const double *l, const double *u,

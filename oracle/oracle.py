@@ -29,6 +29,7 @@ def lib():
             build()
         _LIB = C.CDLL(path)
         _LIB.mipx_oracle_lp_solve_batch.restype = C.c_int
+        _LIB.mipx_oracle_lp_solve_dive_batch.restype = C.c_int
         _LIB.mipx_oracle_most_fractional.restype = C.c_int
         _LIB.mipx_oracle_mip_feasible.restype = C.c_int
         _LIB.mipx_oracle_best_pseudo_cost.restype = C.c_int
@@ -98,20 +99,13 @@ def lp_solve_dive_batch(A, b, c, l, u, vstat, rule, int_idx, cost_l, cost_r, has
     vout = np.zeros((2 * B, n + m), np.int8); iters = np.zeros(2 * B, np.int32)
     npiv = np.zeros(2 * B, np.int32)
     dvar = np.full(B, -1, np.int32); ddir = np.zeros(B, np.int32); dval = np.zeros(B)
-    f = lib().mipx_oracle_lp_solve_dive
-    f.restype = C.c_int
-    at = lambda a, k, t: C.cast(a[k:].ctypes.data, t)
-    for k in range(B):
-        dv = _Dive(int(rule), len(ii), _p(ii, _i32p), _p(cl, _dp), _p(cr, _dp),
-                   he.ctypes.data_as(C.POINTER(C.c_uint8)), float(cutoff),
-                   at(status, B + k, _i32p), at(obj, B + k, _dp), at(x, B + k, _dp),
-                   at(vout, B + k, _i8p), at(iters, B + k, _i32p), at(npiv, B + k, _i32p),
-                   at(dvar, k, _i32p), at(ddir, k, _i32p), at(dval, k, _dp))
-        rc = f(C.c_int(m), C.c_int(n), _p(A, _dp), _p(b, _dp), _p(c, _dp), at(l, k, _dp), at(u, k, _dp),
-               None if vstat is None else at(vstat, k, _i8p), C.c_int(int(max_iter)),
-               at(status, k, _i32p), at(obj, k, _dp), at(x, k, _dp), at(vout, k, _i8p),
-               at(iters, k, _i32p), at(npiv, k, _i32p), C.byref(dv))
-        assert rc == 0, f'oracle lp_solve_dive failed rc={rc}'
+    rc = lib().mipx_oracle_lp_solve_dive_batch(
+        C.c_int(m), C.c_int(n), _p(A, _dp), _p(b, _dp), _p(c, _dp), C.c_int(B), _p(l, _dp), _p(u, _dp),
+        _p(vstat, _i8p), C.c_int(int(max_iter)), C.c_int(int(rule)), C.c_int(len(ii)), _p(ii, _i32p),
+        _p(cl, _dp), _p(cr, _dp), he.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_double(float(cutoff)),
+        _p(status, _i32p), _p(obj, _dp), _p(x, _dp), _p(vout, _i8p), _p(iters, _i32p), _p(npiv, _i32p),
+        _p(dvar, _i32p), _p(ddir, _i32p), _p(dval, _dp))
+    assert rc == 0, f'oracle lp_solve_dive_batch failed rc={rc}'
     return dict(status=status, obj=obj, x=x, vstat=vout, iters=iters, npivots=npiv, dive_var=dvar,
                 dive_dir=ddir, dive_val=dval)
 

@@ -25,7 +25,7 @@ SYMBOLS = [
     'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
     'mipx_tree_solution', 'mipx_tree_set_primal_bound', 'mipx_tree_pseudo_costs', 'mipx_tree_set_pseudo_costs',
     'mipx_tree_set_trace', 'mipx_tree_trace', 'mipx_tree_peek_open', 'mipx_tree_keep_shard',
-    'mipx_tree_set_step_hook', 'mipx_lp_dive_batch',
+    'mipx_tree_set_step_hook', 'mipx_lp_dive_batch', 'mipx_tree_set_dive',
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -46,7 +46,8 @@ class TreeStats(C.Structure):
                 ('probes_solved', C.c_int64), ('pivots', C.c_int64), ('open_nodes', C.c_int64),
                 ('created_nodes', C.c_int64), ('steps', C.c_int64), ('primal_bound', C.c_double),
                 ('dual_bound', C.c_double), ('gap', C.c_double), ('solve_seconds', C.c_double),
-                ('kernel_ms', C.c_double), ('status', C.c_int32), ('has_solution', C.c_int32)]
+                ('kernel_ms', C.c_double), ('status', C.c_int32), ('has_solution', C.c_int32),
+                ('dives', C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -362,6 +363,10 @@ class Tree:
             raise err
         self.problem.ctx.check(rc, 'mipx_tree_solve')
         return st.as_dict()
+
+    def set_dive(self, on=True):
+        """One-level plunge on the register tableau (mipx_tree_set_dive)."""
+        self.problem.ctx.check(lib().mipx_tree_set_dive(self._h, 1 if on else 0), 'mipx_tree_set_dive')
 
     def set_step_hook(self, fn, every_steps=1):
         """Call fn() every `every_steps` frontier steps inside solve(), while the GPU works on the

@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
     KPROF_MARK(6);
     __syncthreads();
     if (g.prof && tid == 0) {
-        for (int k = 0; k < 16; k++) atomicAdd(&g.prof[k], s.prof[k]);
+        for (int k = 0; k < 16; k++) { atomicAdd(&g.prof[k], s.prof[k]); s.prof[k] = 0; }  // (per pass)
         atomicAdd(&g.prof[16], (unsigned long long)iters);
         atomicAdd(&g.prof[17], (unsigned long long)(npiv - iters));
         atomicAdd(&g.prof[18], 1ull);
@@ -1258,33 +1258,53 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
         if (status == 0 && objv < g.dive_cutoff) {
             double bk = -INF;
             int bp = kNoCand, nprobe = 0;
-            for (int base = 0; base < g.n_int; base += 64) {
-                const int k = base + lane;
-                bool need_probe = false;
-                if (k < g.n_int) {
-                    const int i = g.int_idx[k];
-                    const double v = s.key[i];
-                    const double fl = floor(v), ce = ceil(v);
-                    const double dist = fmin(v - fl, ce - v);
-                    const bool frac = dist > kVarEps;
-                    if (g.rule == 0) {
-                        keep(bk, bp, dist, k, frac);
-                    } else if (frac) {
-                        if (g.has_entry[i]) keep(bk, bp, fmin(g.cost_r[i] * (ce - v), g.cost_l[i] * (v - fl)), k, true);
-                        else need_probe = true;
-                    }
-                }
-                nprobe += __popcll(__ballot(need_probe));
+            // n_int <= n <= NP: PJ candidates per lane; the index loads, then the table loads, are
+            // issued together (two memory latencies for the whole rule instead of two per 64 variables)
+            int ci[PJ];
+            bool cv[PJ];
+#pragma unroll
+            for (int kk = 0; kk < PJ; kk++) {
+                const int k = lane + 64 * kk;
+                cv[kk] = k < g.n_int;
+                ci[kk] = g.int_idx[cv[kk] ? k : 0];
+            }
+            double ccl[PJ], ccr[PJ];
+            bool che[PJ];
+#pragma unroll
+            for (int kk = 0; kk < PJ; kk++) {
+                const bool pc = g.rule != 0;
+                che[kk] = pc ? g.has_entry[ci[kk]] != 0 : true;
+                ccl[kk] = pc ? g.cost_l[ci[kk]] : 0.0;
+                ccr[kk] = pc ? g.cost_r[ci[kk]] : 0.0;
+            }
+#pragma unroll
+            for (int kk = 0; kk < PJ; kk++) {
+                const int k = lane + 64 * kk;
+                const double v = s.key[ci[kk]];
+                const double fl = floor(v), ce = ceil(v);
+                const double dist = fmin(v - fl, ce - v);
+                const bool frac = cv[kk] && dist > kVarEps;
+                const double key = g.rule == 0 ? dist : fmin(ccr[kk] * (ce - v), ccl[kk] * (v - fl));
+                keep(bk, bp, key, k, frac && che[kk]);
+                nprobe += __popcll(__ballot(frac && !che[kk]));
             }
             double km;
             const int win = wave_argmax(bk, bp, km);
             if (win != kNoCand && nprobe == 0) {
-                dvar = __builtin_amdgcn_readfirstlane(g.int_idx[win]);
+                // the winner's variable, value and costs sit in lane win % 64, slot win / 64
+                const int wl = win & 63, wk = win >> 6;
+                int t_i;
+                double t_l, t_r;
+                MIPX_PICK(t_i, ci, PJ, wk);
+                MIPX_PICK(t_l, ccl, PJ, wk);
+                MIPX_PICK(t_r, ccr, PJ, wk);
+                dvar = __builtin_amdgcn_readlane(t_i, wl);
+                const double wcl = readlane_f64(t_l, wl), wcr = readlane_f64(t_r, wl);
                 const double v = uniform_f64(s.key[dvar]);
                 const double fl = floor(v), ce = ceil(v);
                 // towards the side the rule expects to cost less (most fractional: the nearer one)
                 if (g.rule == 0) ddir = (v - fl <= ce - v) ? 0 : 1;
-                else ddir = (uniform_f64(g.cost_l[dvar]) * (v - fl) <= uniform_f64(g.cost_r[dvar]) * (ce - v)) ? 0 : 1;
+                else ddir = (wcl * (v - fl) <= wcr * (ce - v)) ? 0 : 1;
                 dbound = ddir == 0 ? fl : ce;
                 bool mine = false;  // a bound change in place needs the variable basic
 #pragma unroll
@@ -1304,6 +1324,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
     __syncthreads();
     }
     if (__builtin_amdgcn_readfirstlane(s.dive_code) < 0) break;
+    KPROF_MARK(11);  // outputs of the node + the branching rule
     pass = 1;
     onode = (size_t)node + (size_t)g.dive_off;
     iters = 0;

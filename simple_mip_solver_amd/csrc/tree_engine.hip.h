@@ -146,16 +146,21 @@ struct StepBuf {
     int32_t *d_ask_count = nullptr;          // [count | pad] then kAskCap entries, inside d_pack
     mipx::ScoreArgs::Ask *d_ask = nullptr;
     size_t ask_off = 0;
-    double *d_obj = nullptr, *d_x = nullptr, *d_bval = nullptr;
+    double *d_obj = nullptr, *d_x = nullptr, *d_bval = nullptr, *d_dval = nullptr;
+    int32_t *d_dvar = nullptr, *d_ddir = nullptr;   // in-place dives of the step (per parent)
     int8_t *d_vout = nullptr;
     // what the host reads back every step, packed so that ONE copy into pinned memory fetches it:
-    // [obj | bval] (f64) then [status | bidx | mipf | nprobe | npiv] (i32), max_batch entries each
+    // [obj | bval] (2 * max_batch f64 each: the batch, then its dive children) [dive_val]
+    // (max_batch f64), then [status | bidx | mipf | nprobe | npiv] (2 * max_batch i32 each)
+    // [dive_var | dive_dir] (max_batch i32 each), then the probe requests
     char *d_pack = nullptr, *h_pack = nullptr;
     size_t pack_bytes = 0;
     int32_t *h_slot = nullptr;  // pinned staging of the batch's pool rows
     hipEvent_t e0 = nullptr, e1 = nullptr, done = nullptr;
     std::vector<int64_t> ids;
     std::vector<int32_t> slots, br_pos, br_slot, br_var, br_child;  // staging kept alive
+    std::vector<int32_t> br2_pos, br2_slot, br2_var, br2_child, dive_slots;  // children of the dive children
+    bool dive = false;  // this step was launched with the in-place dive
     int B = 0;
     bool in_flight = false;
 };
@@ -181,6 +186,8 @@ struct mipx_tree {
     char *h_pres = nullptr;     // pinned mirror of the probe results [pp_obj | pp_status]
     StepBuf buf[2];
     bool table_dirty = false, pipeline = true;
+    bool dive = false;      // mipx_tree_set_dive
+    int64_t dives = 0;      // dive children evaluated in place
     mipx_tree_hook hook = nullptr;
     void *hook_user = nullptr;
     int hook_every = 0;
@@ -270,8 +277,15 @@ void tree_push(mipx_tree *t, int64_t id) {
 
 int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const int8_t *v,
               const int32_t *slot, int max_iter, int32_t *status, double *obj, double *x,
-              int8_t *vout, int32_t *iters, int32_t *npiv, hipStream_t stream = nullptr) {
+              int8_t *vout, int32_t *iters, int32_t *npiv, hipStream_t stream = nullptr,
+              const StepBuf *dive = nullptr) {
     mipx::LpArgs a;
+    if (dive) {  // in-place dive: K4's rule inside K1, children at positions batch .. 2 * batch - 1
+        a.dive = 1; a.dive_off = batch; a.rule = t->rule; a.n_int = t->n_int;
+        a.int_idx = t->d_int_idx; a.cost_l = t->d_cost_l; a.cost_r = t->d_cost_r; a.has_entry = t->d_has;
+        a.dive_cutoff = t->primal;
+        a.dive_var = dive->d_dvar; a.dive_dir = dive->d_ddir; a.dive_val = dive->d_dval;
+    }
     a.m = t->m; a.n = t->n;
     a.A = t->prob->dA; a.b = t->prob->db; a.c = t->prob->dc;
     a.A_stride = a.b_stride = a.c_stride = 0;
@@ -308,6 +322,7 @@ int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false) {
     s.n_probe = S.d_nprobe;
     s.probe_list = S.d_plist;
     s.ask_count = S.d_ask_count; s.ask_cap = kAskCap; s.ask = side ? nullptr : S.d_ask;
+    s.ask_nodes = S.B;  // dive children (positions >= B) are never probed in their own step
     if (!side) HIP_TRY(t->ctx, hipMemsetAsync(S.d_ask_count, 0, 16, t->ctx->stream));
     hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, side ? t->st2 : t->ctx->stream, s);
     HIP_TRY(t->ctx, hipGetLastError());
@@ -382,12 +397,17 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
         HIP_TRY(ctx, hipStreamWaitEvent(st, t->ev_child, 0));
         t->child_pending = false;
     }
+    S.dive = t->dive && pick_cfg(t->m, t->n) != nullptr;
+    if (S.dive) {  // no child / no dive until the kernel says otherwise
+        HIP_TRY(ctx, hipMemsetAsync(S.d_status + B, 0xff, (size_t)B * 4, st));
+        HIP_TRY(ctx, hipMemsetAsync(S.d_dvar, 0xff, (size_t)B * 4, st));
+    }
     HIP_TRY(ctx, hipEventRecord(S.e0, st));
     int rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, S.d_slot, 0, S.d_status, S.d_obj,
-                       S.d_x, S.d_vout, S.d_iters, S.d_npiv);
+                       S.d_x, S.d_vout, S.d_iters, S.d_npiv, nullptr, S.dive ? &S : nullptr);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(S.e1, st));
-    if ((rc = launch_score(t, S, B))) return rc;
+    if ((rc = launch_score(t, S, S.dive ? 2 * B : B))) return rc;
     HIP_TRY(ctx, hipEventRecord(S.done, st));
     return MIPX_OK;
 }
@@ -416,10 +436,14 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     }
     // one copy (pinned destination) for everything the host reads per node
     if ((rc = tree_d2h(t, S.h_pack, S.d_pack, S.pack_bytes))) return rc;
-    const size_t MB = (size_t)t->max_batch;
-    double *obj = (double *)S.h_pack, *bval = obj + MB;
-    int32_t *status = (int32_t *)(bval + MB), *bidx = status + MB, *mipf = bidx + MB, *nprobe = mipf + MB,
-            *npiv = nprobe + MB;
+    const size_t MB = (size_t)t->max_batch, OB = 2 * MB;
+    double *obj = (double *)S.h_pack, *bval = obj + OB, *dval = bval + OB;
+    int32_t *status = (int32_t *)(dval + MB), *bidx = status + OB, *mipf = bidx + OB, *nprobe = mipf + OB,
+            *npiv = nprobe + OB, *dvar = npiv + OB, *ddir = dvar + MB;
+    const int NB = S.dive ? 2 * B : B;  // output positions in use: the batch, then its dive children
+    // a dive child counts when its LP was solved in place and it needs no strong-branching
+    // initialisation of its own (else it is dropped and queued like any other child)
+    auto dived = [&](int k) { return S.dive && dvar[k] >= 0 && status[B + k] >= 0 && nprobe[B + k] == 0; };
     t->lps += B;
     for (int k = 0; k < B; k++) t->pivots += npiv[k];
     t->phase_ms[1] += ms_since(tp); tp = now();
@@ -533,6 +557,11 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
                     pc_update(t, nd.b_idx, nd.b_dir, status[k], obj[k], nd.dual_bound, vc);
                     changed = true;
                 }
+                if (dived(k)) {  // the dive child: the update for the branch that made it
+                    const double vc = ddir[k] == 0 ? dval[k] - std::floor(dval[k]) : std::ceil(dval[k]) - dval[k];
+                    pc_update(t, dvar[k], ddir[k], status[B + k], obj[B + k], obj[k], vc);
+                    changed = true;
+                }
             } else {
                 e += 0;
             }
@@ -549,55 +578,89 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             HIP_TRY(ctx, hipMemcpyAsync(cr, t->cost_r.data(), (size_t)n * 8, hipMemcpyHostToDevice, ps));
             HIP_TRY(ctx, hipMemcpyAsync(ch, t->has_entry.data(), (size_t)n, hipMemcpyHostToDevice, ps));
             if (!use_side) t->table_dirty = false;
-            if ((rc = launch_score(t, S, B, use_side))) return rc;
+            if ((rc = launch_score(t, S, NB, use_side))) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ps));
-            if ((rc = tree_d2h(t, bidx, S.d_bidx, (size_t)B * 4))) return rc;
-            if ((rc = tree_d2h(t, bval, S.d_bval, (size_t)B * 8))) return rc;
+            if ((rc = tree_d2h(t, bidx, S.d_bidx, (size_t)NB * 4))) return rc;
+            if ((rc = tree_d2h(t, bval, S.d_bval, (size_t)NB * 8))) return rc;
         }
     }
 
     t->phase_ms[2] += ms_since(tp); tp = now();
-    // 4. the reference's _evaluate_node bookkeeping, node by node
+    // 4. the reference's _evaluate_node bookkeeping, node by node (a dive child right after its
+    //    parent: it was solved in the same workgroup)
     std::vector<int32_t> &br_pos = S.br_pos, &br_slot = S.br_slot, &br_var = S.br_var, &br_child = S.br_child;
+    std::vector<int32_t> &br2_pos = S.br2_pos, &br2_slot = S.br2_slot, &br2_var = S.br2_var,
+                         &br2_child = S.br2_child, &dive_slots = S.dive_slots;
     br_pos.clear(); br_slot.clear(); br_var.clear(); br_child.clear();
+    br2_pos.clear(); br2_slot.clear(); br2_var.clear(); br2_child.clear(); dive_slots.clear();
     int incumbent_pos = -1;
-    for (int k = 0; k < B; k++) {
-        const int64_t id = ids[k];
+    // One evaluated node at output position pos.  level 0: a node of the batch (pool row
+    // `slot`); level 1: a dive child.  Returns the id of the child that was solved in place by
+    // the dive (to be evaluated next), or -1.
+    auto evaluate = [&](int64_t id, int pos, int32_t slot, int level, int &err) -> int64_t {
         t->evaluated++;
-        const bool lp_feasible = status[k] == 0 || status[k] == 2;
-        if (status[k] == 2) t->unbounded = true;
+        const bool lp_feasible = status[pos] == 0 || status[pos] == 2;
+        if (status[pos] == 2) t->unbounded = true;
         int branched_on = -1;
-        double leaf_value = lp_feasible ? obj[k] : inf;
-        if (lp_feasible && obj[k] < t->primal) {
-            if (mipf[k]) {
-                t->primal = obj[k];
-                incumbent_pos = k;
-            } else if (bidx[k] >= 0) {
-                if (t->free_slots.size() < 2) return fail(ctx, MIPX_ENOMEM, "tree: node pool exhausted");
-                branched_on = bidx[k];
-                const double xv = bval[k];
+        int64_t dive_child = -1;
+        double leaf_value = lp_feasible ? obj[pos] : inf;
+        if (lp_feasible && obj[pos] < t->primal) {
+            const bool take_dive = level == 0 && dived(pos);
+            const int bvar = take_dive ? dvar[pos] : bidx[pos];  // a dive has already branched
+            if (mipf[pos]) {
+                t->primal = obj[pos];
+                incumbent_pos = pos;
+            } else if (bvar >= 0) {
+                if (t->free_slots.size() < 2) {
+                    err = fail(ctx, MIPX_ENOMEM, "tree: node pool exhausted");
+                    return -1;
+                }
+                branched_on = bvar;
+                const double xv = take_dive ? dval[pos] : bval[pos];
                 for (int dir = 0; dir < 2; dir++) {
                     NodeRec c;
-                    c.dual_bound = obj[k];
+                    c.dual_bound = obj[pos];
                     c.depth = t->nodes[id].depth + 1;
                     c.key = t->search == 0 ? c.dual_bound : -(double)c.depth;
                     c.b_idx = branched_on; c.b_dir = dir; c.b_val = xv;
                     c.slot = t->free_slots.back();
                     t->free_slots.pop_back();
-                    br_child.push_back(c.slot);
+                    (level == 0 ? br_child : br2_child).push_back(c.slot);
                     t->nodes.push_back(c);
-                    tree_push(t, (int64_t)t->nodes.size() - 1);
+                    const int64_t cid = (int64_t)t->nodes.size() - 1;
+                    if (take_dive && dir == ddir[pos]) {
+                        dive_child = cid;  // already solved: never enters the queue
+                        if ((size_t)cid >= t->is_open.size()) t->is_open.resize(cid + 1, 0);
+                    } else {
+                        tree_push(t, cid);
+                    }
                 }
-                br_pos.push_back(k);
-                br_slot.push_back(slots[k]);
-                br_var.push_back(branched_on);
+                (level == 0 ? br_pos : br2_pos).push_back(pos);
+                (level == 0 ? br_slot : br2_slot).push_back(slot);
+                (level == 0 ? br_var : br2_var).push_back(branched_on);
                 leaf_value = inf;  // no longer a leaf
             }
         }
         if (branched_on < 0) t->closed_min = std::fmin(t->closed_min, leaf_value);
         if (t->trace) {
-            t->tr_id.push_back(id); t->tr_status.push_back(status[k]);
-            t->tr_bidx.push_back(branched_on); t->tr_obj.push_back(obj[k]);
+            t->tr_id.push_back(id); t->tr_status.push_back(status[pos]);
+            t->tr_bidx.push_back(branched_on); t->tr_obj.push_back(obj[pos]);
+        }
+        return dive_child;
+    };
+    for (int k = 0; k < B; k++) {
+        int err = MIPX_OK;
+        const int64_t cid = evaluate(ids[k], k, slots[k], 0, err);
+        if (err) return err;
+        if (cid >= 0) {
+            const int32_t cslot = t->nodes[cid].slot;
+            t->lps++;
+            t->dives++;
+            t->pivots += npiv[B + k];
+            evaluate(cid, B + k, cslot, 1, err);
+            if (err) return err;
+            dive_slots.push_back(cslot);  // its record row feeds its own children below
+            t->nodes[cid].slot = -1;
         }
     }
     if (incumbent_pos >= 0) {
@@ -615,26 +678,36 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         t->anchor_set = true;
     }
     // 5. children records on the device, then release the evaluated nodes' rows
-    const int P = (int)br_pos.size();
+    const int P = (int)br_pos.size(), P2 = (int)br2_pos.size();
     if (P > 0) {
         // when steps overlap this runs on its own stream, beside the node LPs of the step in flight
         // (it writes fresh pool rows only); the next launch waits for it
         hipStream_t cs = overlapped ? t->st3 : st;
         if (overlapped) HIP_TRY(ctx, hipStreamSynchronize(t->st3));  // h_pairs / d_pairs free again
-        std::memcpy(t->h_pairs, br_slot.data(), (size_t)P * 4);
-        std::memcpy(t->h_pairs + P, br_pos.data(), (size_t)P * 4);
-        std::memcpy(t->h_pairs + 2 * P, br_var.data(), (size_t)P * 4);
-        std::memcpy(t->h_pairs + 3 * P, br_child.data(), (size_t)P * 8);
-        HIP_TRY(ctx, hipMemcpyAsync(t->d_pairs, t->h_pairs, (size_t)P * 20, hipMemcpyHostToDevice, cs));
-        mipx::ChildArgs ca;
-        ca.n = n; ca.m = t->m; ca.count = P;
-        ca.src_l = t->pool_l; ca.src_u = t->pool_u;
-        ca.parent_slot = t->d_pairs; ca.parent_pos = t->d_pairs + P; ca.var = t->d_pairs + 2 * P;
-        ca.x = S.d_x; ca.vstat = S.d_vout;
-        ca.dst_l = t->pool_l; ca.dst_u = t->pool_u; ca.dst_v = t->pool_v;
-        ca.child_slot = t->d_pairs + 3 * P;
-        hipLaunchKernelGGL(mipx::make_children, dim3(2 * P), dim3(256), 0, cs, ca);
-        HIP_TRY(ctx, hipGetLastError());
+        auto children = [&](int cnt, const std::vector<int32_t> &cslot, const std::vector<int32_t> &cpos,
+                            const std::vector<int32_t> &cvar, const std::vector<int32_t> &cchild,
+                            int32_t *hp, int32_t *dp) -> int {
+            std::memcpy(hp, cslot.data(), (size_t)cnt * 4);
+            std::memcpy(hp + cnt, cpos.data(), (size_t)cnt * 4);
+            std::memcpy(hp + 2 * cnt, cvar.data(), (size_t)cnt * 4);
+            std::memcpy(hp + 3 * cnt, cchild.data(), (size_t)cnt * 8);
+            HIP_TRY(ctx, hipMemcpyAsync(dp, hp, (size_t)cnt * 20, hipMemcpyHostToDevice, cs));
+            mipx::ChildArgs ca;
+            ca.n = n; ca.m = t->m; ca.count = cnt;
+            ca.src_l = t->pool_l; ca.src_u = t->pool_u;
+            ca.parent_slot = dp; ca.parent_pos = dp + cnt; ca.var = dp + 2 * cnt;
+            ca.x = S.d_x; ca.vstat = S.d_vout;
+            ca.dst_l = t->pool_l; ca.dst_u = t->pool_u; ca.dst_v = t->pool_v;
+            ca.child_slot = dp + 3 * cnt;
+            hipLaunchKernelGGL(mipx::make_children, dim3(2 * cnt), dim3(256), 0, cs, ca);
+            HIP_TRY(ctx, hipGetLastError());
+            return MIPX_OK;
+        };
+        const size_t half = 5 * (size_t)t->max_batch;  // second half of the staging: dive children's children
+        if ((rc = children(P, br_slot, br_pos, br_var, br_child, t->h_pairs, t->d_pairs))) return rc;
+        // (same stream: the records of the dive children exist before their children are derived)
+        if (P2 > 0 && (rc = children(P2, br2_slot, br2_pos, br2_var, br2_child, t->h_pairs + half, t->d_pairs + half)))
+            return rc;
         if (overlapped) {
             HIP_TRY(ctx, hipEventRecord(t->ev_child, t->st3));
             t->child_pending = true;
@@ -642,6 +715,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             HIP_TRY(ctx, hipStreamSynchronize(st));
         }
     }
+    for (int32_t sl : dive_slots) t->free_slots.push_back(sl);
     for (int k = 0; k < B; k++) {
         t->free_slots.push_back(slots[k]);
         t->nodes[ids[k]].slot = -1;
@@ -683,8 +757,8 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     rc |= dmalloc(ctx, &t->pool_l, cap * n); rc |= dmalloc(ctx, &t->pool_u, cap * n);
     rc |= dmalloc(ctx, &t->pool_v, cap * nv);
     rc |= dmalloc(ctx, &t->d_int_idx, (size_t)n_int);
-    rc |= dmalloc(ctx, &t->d_pairs, 5 * (pc / 2 > B ? pc / 2 : B));
-    rc |= dmalloc(ctx, &t->d_pairs2, 5 * (pc / 2 > B ? pc / 2 : B));
+    rc |= dmalloc(ctx, &t->d_pairs, 5 * (pc / 2 > 2 * B ? pc / 2 : 2 * B));   // (second half: children of dive children)
+    rc |= dmalloc(ctx, &t->d_pairs2, 5 * (pc / 2 > 2 * B ? pc / 2 : 2 * B));
     rc |= dmalloc(ctx, &t->d_cost_l2, n); rc |= dmalloc(ctx, &t->d_cost_r2, n); rc |= dmalloc(ctx, &t->d_has2, n);
     // The side streams carry short, latency-critical work (probes, re-scoring, child records) that
     // must overtake the 2 ms node-LP launch queued on the main stream.  HIP multiplexes the streams
@@ -696,25 +770,27 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     if (hipStreamCreateWithPriority(&t->st2, hipStreamNonBlocking, prio_greatest) != hipSuccess) rc |= MIPX_EHIP;
     if (hipStreamCreateWithPriority(&t->st3, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&t->ev_child, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void **)&t->h_pairs, 5 * B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
+        hipHostMalloc((void **)&t->h_pairs, 10 * B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
     for (StepBuf &S : t->buf) {
         rc |= dmalloc(ctx, &S.d_slot, B);
-        rc |= dmalloc(ctx, &S.d_iters, B);
-        S.ask_off = (B * (2 * 8 + 5 * 4) + 15) / 16 * 16;
+        // per-node outputs have 2 * B rows: the batch, then its dive children
+        rc |= dmalloc(ctx, &S.d_iters, 2 * B);
+        S.ask_off = (2 * B * (2 * 8 + 5 * 4) + B * (8 + 2 * 4) + 15) / 16 * 16;
         S.pack_bytes = S.ask_off + 16 + (size_t)kAskCap * sizeof(mipx::ScoreArgs::Ask);
         rc |= dmalloc(ctx, &S.d_pack, S.pack_bytes);
         if (hipHostMalloc((void **)&S.h_pack, S.pack_bytes, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc((void **)&S.h_slot, B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
         if (S.d_pack) {
-            S.d_obj = (double *)S.d_pack; S.d_bval = S.d_obj + B;
-            S.d_status = (int32_t *)(S.d_bval + B); S.d_bidx = S.d_status + B; S.d_mipf = S.d_bidx + B;
-            S.d_nprobe = S.d_mipf + B; S.d_npiv = S.d_nprobe + B;
+            S.d_obj = (double *)S.d_pack; S.d_bval = S.d_obj + 2 * B; S.d_dval = S.d_bval + 2 * B;
+            S.d_status = (int32_t *)(S.d_dval + B); S.d_bidx = S.d_status + 2 * B; S.d_mipf = S.d_bidx + 2 * B;
+            S.d_nprobe = S.d_mipf + 2 * B; S.d_npiv = S.d_nprobe + 2 * B;
+            S.d_dvar = S.d_npiv + 2 * B; S.d_ddir = S.d_dvar + B;
             S.d_ask_count = (int32_t *)((char *)S.d_pack + S.ask_off);
             S.d_ask = (mipx::ScoreArgs::Ask *)((char *)S.d_pack + S.ask_off + 16);
         }
-        rc |= dmalloc(ctx, &S.d_plist, B * (size_t)(n_int ? n_int : 1));
-        rc |= dmalloc(ctx, &S.d_x, B * n);
-        rc |= dmalloc(ctx, &S.d_vout, B * nv);
+        rc |= dmalloc(ctx, &S.d_plist, 2 * B * (size_t)(n_int ? n_int : 1));
+        rc |= dmalloc(ctx, &S.d_x, 2 * B * n);
+        rc |= dmalloc(ctx, &S.d_vout, 2 * B * nv);
         if (hipEventCreate(&S.e0) != hipSuccess || hipEventCreate(&S.e1) != hipSuccess ||
             hipEventCreate(&S.done) != hipSuccess) rc |= MIPX_EHIP;
     }
@@ -891,6 +967,15 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
     return MIPX_OK;
 }
 
+int mipx_tree_set_dive(mipx_tree *t, int on) {
+    if (!t) return MIPX_EINVAL;
+    if (on && t->max_batch == 1)
+        return fail(t->ctx, MIPX_EINVAL, "mipx_tree_set_dive: the exact mode (max_batch = 1) reproduces the "
+                                         "reference's node order and cannot dive");
+    t->dive = on != 0;
+    return MIPX_OK;
+}
+
 int mipx_tree_set_step_hook(mipx_tree *t, mipx_tree_hook fn, void *user, int every_steps) {
     if (!t || (fn && every_steps < 1)) return MIPX_EINVAL;
     t->hook = fn;
@@ -915,6 +1000,7 @@ int mipx_tree_get_stats(mipx_tree *t, mipx_tree_stats *out) {
     out->kernel_ms = t->kernel_ms;
     out->status = t->status;
     out->has_solution = t->have_x ? 1 : 0;
+    out->dives = t->dives;
     return MIPX_OK;
 }
 

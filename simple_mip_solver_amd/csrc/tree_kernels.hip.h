@@ -31,6 +31,7 @@ struct ScoreArgs {
     // to probe_list).  ask == nullptr: not wanted (re-scoring).
     int32_t *ask_count;
     int32_t ask_cap;
+    int32_t ask_nodes;              // only nodes < ask_nodes file requests
     struct Ask { int32_t node, k; double x; } *ask;
 };
 
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(64) void branch_score(ScoreArgs g) {
         g.branch_val[node] = bvar < 0 ? 0.0 : x[bvar];
         g.n_probe[node] = nprobe;
     }
-    if (g.ask != nullptr && nprobe > 0) {  // wave-uniform; rare once the table has filled
+    if (g.ask != nullptr && nprobe > 0 && node < g.ask_nodes) {  // wave-uniform; rare once the table has filled
         int off = 0;
         if (lane == 0) off = atomicAdd(g.ask_count, nprobe);
         off = __shfl(off, 0);

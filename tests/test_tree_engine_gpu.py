@@ -246,3 +246,36 @@ def test_step_hook_runs_inside_the_step_loop():
     assert t3.solve(mip_gap=0.0, frontier_batch=8, max_steps=2)['status'] == 4
     with pytest.raises(_ffi.MipxError, match='MIPX_EINVAL'):
         t3.set_step_hook(lambda: False, 0)
+
+
+@pytest.mark.parametrize('rule', ['most fractional', 'pseudo cost'])
+def test_dive_reaches_the_same_optimum(rule):
+    """mipx_tree_set_dive: the workgroup that solved a node also solves one child on the tableau it
+    holds.  A different node order, the same optimum; every dive child is a real evaluated node."""
+    from simple_mip_solver_amd import _ffi
+    ctx = _ffi.default_context()
+    for n, m, seed in ((20, 8, 10), (24, 10, 11), (30, 12, 3), (40, 16, 3), (48, 20, 0)):
+        A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=seed)
+        prob = _ffi.Problem(ctx, A, b, c)
+        out = {}
+        for dive in (False, True):
+            t = _ffi.Tree(prob, ints, l, u, branch_rule=rule, max_batch=64, pool_capacity=1 << 17)
+            t.set_anchor_mode(True)
+            t.set_dive(dive)
+            st = t.solve(mip_gap=0.0, frontier_batch=64, node_limit=100000)
+            out[dive] = (st, t.solution() if st['has_solution'] else None)
+            t.close()
+        (s0, x0), (s1, x1) = out[False], out[True]
+        assert s0['status'] == s1['status'] == 1, (s0, s1)
+        assert isclose(s0['primal_bound'], s1['primal_bound'], abs_tol=1e-6)
+        assert s0['dives'] == 0 and s1['dives'] > 0
+        assert s1['lp_solved'] == s1['evaluated_nodes'] and s1['dives'] < s1['evaluated_nodes']
+        assert np.max(np.abs(x1[ints] - np.round(x1[ints]))) <= 1e-4
+        assert np.all(A @ x1 >= b - 1e-6) and isclose(float(c @ x1), s1['primal_bound'], abs_tol=1e-6)
+        prob.close()
+    # the exact mode reproduces the reference's node order: no dive there
+    A, b, c, l, u, ints = random_dense_milp_arrays(24, 10, seed=10)
+    prob = _ffi.Problem(ctx, A, b, c)
+    t = _ffi.Tree(prob, ints, l, u, max_batch=1)
+    with pytest.raises(_ffi.MipxError, match='MIPX_EINVAL'):
+        t.set_dive(True)
