@@ -579,8 +579,12 @@ _Pragma("unroll")                                                               
 // tableau waves (whole rows of T in registers, rank-1 updates).  They meet at three barriers per
 // simplex iteration (row chosen / row published / column chosen) and two per refactorisation
 // pivot; the pivot column goes to the control wave through s.alpha and the s.seq counter.
-template <int NW, int R, int C, int MP, bool DIVE = false>
-__global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
+// The body is instantiated twice, once per role (CTL): with the role a compile-time constant the
+// control wave's copy never sees the register tableau (T is dead there), so the selections get
+// the registers the tableau would otherwise pin across them, and the tableau waves' copy carries
+// none of the control wave's borders.  Same source, same barriers.
+template <int NW, int R, int C, int MP, bool DIVE, bool CTL>
+__device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R, C, MP> &s) {
     constexpr int NT = 64 * (NW + 1);
     constexpr int NG = 4 * NW;          // row groups of the workgroup (4 per tableau wave)
     constexpr int NP = 16 * C;          // padded columns: 16 column lanes x C columns each
@@ -588,12 +592,11 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
     static_assert(MP <= NG * R, "the tableau waves must cover every row");
     constexpr int PI = (MP + 63) / 64;  // rows per lane of the control wave
     constexpr int PJ = NP / 64;         // columns per lane of the control wave
-    __shared__ Smem<NW, R, C, MP> s;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool ctl = wave == 0;
+    const int wave = CTL ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool ctl = CTL;
     const int tw = wave - 1;  // tableau wave index
     const int cl = lane & 15;                 // tableau lanes: column lane,
     const int grp = 4 * tw + (lane >> 4);     //   row group (rows grp + NG*ii)
@@ -1330,6 +1333,13 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
     iters = 0;
     npiv = 0;
     }
+}
+
+template <int NW, int R, int C, int MP, bool DIVE = false>
+__global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
+    __shared__ Smem<NW, R, C, MP> s;
+    if (threadIdx.x < 64) lp_dual_simplex_role<NW, R, C, MP, DIVE, true>(g, s);   // wave 0: control
+    else lp_dual_simplex_role<NW, R, C, MP, DIVE, false>(g, s);                   // tableau waves
 }
 
 #undef MIPX_PUBLISH_COL

@@ -158,6 +158,7 @@ struct StepBuf {
     int32_t *h_slot = nullptr;  // pinned staging of the batch's pool rows
     hipEvent_t e0 = nullptr, e1 = nullptr, done = nullptr;
     std::vector<int64_t> ids;
+    std::vector<NodeRec> recs;  // the batch's node records, copied at pop time (one random access per node and step)
     std::vector<int32_t> slots, br_pos, br_slot, br_var, br_child;  // staging kept alive
     std::vector<int32_t> br2_pos, br2_slot, br2_var, br2_child, dive_slots;  // children of the dive children
     bool dive = false;  // this step was launched with the in-place dive
@@ -270,9 +271,11 @@ void tree_queue_ids(const mipx_tree *t, std::vector<int64_t> &out) {
 void tree_push(mipx_tree *t, int64_t id) {
     if (t->use_bq) t->bq.push(t->nodes[id].key, id);
     else t->heap.push(t->nodes[id].key, id);
-    if ((size_t)id >= t->is_open.size()) t->is_open.resize(id + 1, 0);
-    t->is_open[id] = 1;
-    if (t->search != 0) t->open_bounds.push({t->nodes[id].dual_bound, id});
+    if (t->search != 0) {  // depth first: the dual bound comes from a lazy heap over the open nodes
+        if ((size_t)id >= t->is_open.size()) t->is_open.resize(id + 1, 0);
+        t->is_open[id] = 1;
+        t->open_bounds.push({t->nodes[id].dual_bound, id});
+    }
 }
 
 int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const int8_t *v,
@@ -354,25 +357,32 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
     std::vector<int32_t> &slots = S.slots;
     ids.clear();
     slots.clear();
+    S.recs.clear();
     S.B = 0;
     S.in_flight = false;
     auto take = [&](int64_t id) {
-        t->is_open[id] = 0;
+        if (t->search != 0) t->is_open[id] = 0;
         NodeRec &nd = t->nodes[id];
+        const int32_t slot = nd.slot;
+        nd.slot = -1;  // (the row itself is released when the step is finished)
         if (!(nd.dual_bound < t->primal)) {
             t->closed_min = std::fmin(t->closed_min, nd.dual_bound);
-            t->free_slots.push_back(nd.slot);
-            nd.slot = -1;
+            t->free_slots.push_back(slot);
             return;
         }
         ids.push_back(id);
-        slots.push_back(nd.slot);
+        slots.push_back(slot);
+        S.recs.push_back(nd);
     };
     if (t->use_bq) {
         while ((int)ids.size() < want && !t->bq.empty()) {
             t->popped.clear();
             t->bq.pop_batch((size_t)want - ids.size(), t->popped);
-            for (const BucketQueue::Item &it : t->popped) take(it.id);
+            const size_t np = t->popped.size();
+            for (size_t i = 0; i < np; i++) {  // the node table is far bigger than the caches
+                if (i + 16 < np) __builtin_prefetch(&t->nodes[t->popped[i + 16].id], 1);
+                take(t->popped[i].id);
+            }
         }
     } else {
         while ((int)ids.size() < want && !tree_queue_empty(t)) take(t->heap.pop());
@@ -539,7 +549,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         bool changed = false;
         for (int k = 0; k < B; k++) {
             const bool lp_feasible = status[k] == 0 || status[k] == 2;
-            const NodeRec &nd = t->nodes[ids[k]];
+            const NodeRec &nd = S.recs[k];
             bool own_probed = false;
             if (lp_feasible) {
                 for (int q = 0; q < nprobe[k]; q++, e++) {
@@ -597,7 +607,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     // One evaluated node at output position pos.  level 0: a node of the batch (pool row
     // `slot`); level 1: a dive child.  Returns the id of the child that was solved in place by
     // the dive (to be evaluated next), or -1.
-    auto evaluate = [&](int64_t id, int pos, int32_t slot, int level, int &err) -> int64_t {
+    auto evaluate = [&](int64_t id, int pos, int32_t slot, int level, int depth, int &err) -> int64_t {
         t->evaluated++;
         const bool lp_feasible = status[pos] == 0 || status[pos] == 2;
         if (status[pos] == 2) t->unbounded = true;
@@ -620,7 +630,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
                 for (int dir = 0; dir < 2; dir++) {
                     NodeRec c;
                     c.dual_bound = obj[pos];
-                    c.depth = t->nodes[id].depth + 1;
+                    c.depth = depth + 1;
                     c.key = t->search == 0 ? c.dual_bound : -(double)c.depth;
                     c.b_idx = branched_on; c.b_dir = dir; c.b_val = xv;
                     c.slot = t->free_slots.back();
@@ -630,7 +640,6 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
                     const int64_t cid = (int64_t)t->nodes.size() - 1;
                     if (take_dive && dir == ddir[pos]) {
                         dive_child = cid;  // already solved: never enters the queue
-                        if ((size_t)cid >= t->is_open.size()) t->is_open.resize(cid + 1, 0);
                     } else {
                         tree_push(t, cid);
                     }
@@ -650,14 +659,14 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     };
     for (int k = 0; k < B; k++) {
         int err = MIPX_OK;
-        const int64_t cid = evaluate(ids[k], k, slots[k], 0, err);
+        const int64_t cid = evaluate(ids[k], k, slots[k], 0, S.recs[k].depth, err);
         if (err) return err;
         if (cid >= 0) {
             const int32_t cslot = t->nodes[cid].slot;
             t->lps++;
             t->dives++;
             t->pivots += npiv[B + k];
-            evaluate(cid, B + k, cslot, 1, err);
+            evaluate(cid, B + k, cslot, 1, S.recs[k].depth + 1, err);
             if (err) return err;
             dive_slots.push_back(cslot);  // its record row feeds its own children below
             t->nodes[cid].slot = -1;
@@ -716,10 +725,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         }
     }
     for (int32_t sl : dive_slots) t->free_slots.push_back(sl);
-    for (int k = 0; k < B; k++) {
-        t->free_slots.push_back(slots[k]);
-        t->nodes[ids[k]].slot = -1;
-    }
+    for (int k = 0; k < B; k++) t->free_slots.push_back(slots[k]);
     (void)nv;
     t->phase_ms[4] += ms_since(tp);
     return MIPX_OK;
@@ -1070,7 +1076,7 @@ int mipx_tree_keep_shard(mipx_tree *t, int rank, int world) {
     while (!t->open_bounds.empty()) t->open_bounds.pop();
     for (size_t pos = 0; pos < old.size(); pos++) {
         const int64_t id = old[pos];
-        t->is_open[id] = 0;
+        if (t->search != 0) t->is_open[id] = 0;
         if ((int)(pos % (size_t)world) == rank) {
             tree_push(t, id);
         } else {
