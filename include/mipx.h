@@ -212,6 +212,8 @@ typedef struct mipx_tree_stats {
                                  4 stopped on iterations or time */
     int32_t has_solution;
     int64_t dives;            /* of lp_solved / evaluated_nodes: children solved in place by the dive */
+    int32_t pool_exhausted;   /* 1: the search stopped (status 4) because pool_capacity is used up */
+    int32_t reserved;
 } mipx_tree_stats;
 
 /*

@@ -47,7 +47,7 @@ class TreeStats(C.Structure):
                 ('created_nodes', C.c_int64), ('steps', C.c_int64), ('primal_bound', C.c_double),
                 ('dual_bound', C.c_double), ('gap', C.c_double), ('solve_seconds', C.c_double),
                 ('kernel_ms', C.c_double), ('status', C.c_int32), ('has_solution', C.c_int32),
-                ('dives', C.c_int64)]
+                ('dives', C.c_int64), ('pool_exhausted', C.c_int32), ('reserved', C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -253,6 +253,10 @@ class BranchAndBound(BaseAlgorithm):
                                 max_seconds=0.0 if self.max_run_time == INF else self.max_run_time,
                                 frontier_batch=self.frontier_batch)
         self._native_stats = st
+        if st['pool_exhausted']:
+            import warnings
+            warnings.warn('the GPU node pool is full (pool_capacity=%d): the search stopped with the bounds '
+                          'found so far; pass a larger pool_capacity' % self._pool_capacity, RuntimeWarning)
         self.solve_time = st['solve_seconds']
         self.evaluated_nodes = st['evaluated_nodes']
         self.primal_bound = st['primal_bound']

@@ -188,6 +188,7 @@ struct mipx_tree {
     StepBuf buf[2];
     bool table_dirty = false, pipeline = true;
     bool dive = false;      // mipx_tree_set_dive
+    bool pool_exhausted = false;
     int64_t dives = 0;      // dive children evaluated in place
     mipx_tree_hook hook = nullptr;
     void *hook_user = nullptr;
@@ -917,10 +918,22 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
         return false;
     };
     auto batch_size = [&](int64_t inflight) {
-        int want = frontier_batch;
+        int64_t want = frontier_batch;
         if (node_limit > 0 && node_limit - t->evaluated - inflight < want)
-            want = (int)(node_limit - t->evaluated - inflight);
-        return want;
+            want = node_limit - t->evaluated - inflight;
+        // every evaluated node may need pool rows for two children (four with the dive: the child
+        // solved in place branches too); a step in flight has the same claim.  When the pool
+        // cannot take a single node's children the search stops (status 4, stats.pool_exhausted).
+        const int64_t per = t->dive ? 4 : 2;
+        const int64_t room = ((int64_t)t->free_slots.size() - per * inflight) / per;
+        if (room < want) {
+            want = room > 0 ? room : 0;
+            if (want == 0 && inflight == 0) {
+                t->pool_exhausted = true;
+                (void)fail(ctx, MIPX_ENOMEM, "tree: node pool exhausted (search stopped; raise pool_capacity)");
+            }
+        }
+        return (int)want;
     };
     if (!tree_queue_empty(t) && !stop_now(0)) {
         int rc = tree_launch(t, t->buf[cur], batch_size(0));
@@ -1007,6 +1020,8 @@ int mipx_tree_get_stats(mipx_tree *t, mipx_tree_stats *out) {
     out->status = t->status;
     out->has_solution = t->have_x ? 1 : 0;
     out->dives = t->dives;
+    out->pool_exhausted = t->pool_exhausted ? 1 : 0;
+    out->reserved = 0;
     return MIPX_OK;
 }
 

@@ -279,3 +279,29 @@ def test_dive_reaches_the_same_optimum(rule):
     t = _ffi.Tree(prob, ints, l, u, max_batch=1)
     with pytest.raises(_ffi.MipxError, match='MIPX_EINVAL'):
         t.set_dive(True)
+
+
+def test_full_node_pool_stops_the_search_cleanly():
+    """A pool too small for the tree: the engine shrinks its batches to what fits and, when not even
+    one node's children fit, stops with status 4 and valid bounds instead of failing."""
+    from simple_mip_solver_amd import _ffi
+    ctx = _ffi.default_context()
+    A, b, c, l, u, ints = random_dense_milp_arrays(40, 16, seed=3)   # needs about 4000 nodes
+    prob = _ffi.Problem(ctx, A, b, c)
+    big = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=64, pool_capacity=1 << 16)
+    ref = big.solve(mip_gap=0.0, frontier_batch=64)
+    assert ref['status'] == 1 and not ref['pool_exhausted']
+    for dive in (False, True):
+        t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=64, pool_capacity=256)
+        t.set_dive(dive)
+        st = t.solve(mip_gap=0.0, frontier_batch=64)
+        assert st['status'] == 4 and st['pool_exhausted'] == 1
+        assert st['open_nodes'] > 0 and st['dual_bound'] <= ref['primal_bound'] + 1e-9
+        assert st['primal_bound'] >= ref['primal_bound'] - 1e-9        # any incumbent found is feasible
+        assert t.solve(mip_gap=0.0, frontier_batch=64)['status'] == 4   # and it stays stopped
+    # the Python driver passes it on as a warning
+    bb = BranchAndBound(random_model(40, 16, 3), PseudoCostBranchNode, pseudo_costs={}, gomory_cuts=False,
+                        frontier_batch=64, pool_capacity=256)
+    with pytest.warns(RuntimeWarning, match='node pool is full'):
+        bb.solve()
+    assert bb.status == 'stopped on iterations or time'
