@@ -51,7 +51,7 @@ def algorithmic_bytes(m, n, lps, pivots, dives=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=60)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=8192, help='frontier nodes per step per GPU')
     ap.add_argument('--vars', type=int, default=256)
