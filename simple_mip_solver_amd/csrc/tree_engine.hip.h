@@ -24,6 +24,7 @@ struct NodeRec {
     int32_t depth;
     int32_t b_idx;       // variable branched on to create this node (-1 root)
     int32_t b_dir;       // 0 left (x <= floor), 1 right (x >= ceil)
+    int32_t born = 0;    // step that created the node (MIPX_TREE_PROFILE: age histogram)
 };
 
 // CPython's heapq on node ids (Lib/heapq.py heappush/heappop/_siftdown/_siftup), so that ties are
@@ -189,6 +190,8 @@ struct mipx_tree {
     bool table_dirty = false, pipeline = true;
     bool dive = false;      // mipx_tree_set_dive
     bool pool_exhausted = false;
+    int64_t age_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // popped nodes by age in steps (1 = created by the previous step)
+    int64_t depth_sum = 0;
     int64_t dives = 0;      // dive children evaluated in place
     mipx_tree_hook hook = nullptr;
     void *hook_user = nullptr;
@@ -224,8 +227,8 @@ struct mipx_tree {
     std::vector<double> tr_obj;
     bool trace = false;
     bool anchor_mode = false, anchor_set = false;
-    double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double probe_ms[4] = {0, 0, 0, 0};  // probes phase: read-back of askers | enqueue | wait | results  // MIPX_TREE_PROFILE=1: host-side breakdown
+    double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // MIPX_TREE_PROFILE=1: host-side breakdown
+    double probe_ms[4] = {0, 0, 0, 0};  // probes phase: requests | enqueue | wait | results
 };
 
 namespace {
@@ -374,6 +377,7 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
         ids.push_back(id);
         slots.push_back(slot);
         S.recs.push_back(nd);
+        { const int64_t age = t->steps + 1 - nd.born; t->age_hist[age < 1 ? 0 : age > 7 ? 7 : age]++; t->depth_sum += nd.depth; }
     };
     if (t->use_bq) {
         while ((int)ids.size() < want && !t->bq.empty()) {
@@ -634,6 +638,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
                     c.depth = depth + 1;
                     c.key = t->search == 0 ? c.dual_bound : -(double)c.depth;
                     c.b_idx = branched_on; c.b_dir = dir; c.b_val = xv;
+                    c.born = (int32_t)t->steps;
                     c.slot = t->free_slots.back();
                     t->free_slots.pop_back();
                     (level == 0 ? br_child : br2_child).push_back(c.slot);
@@ -973,6 +978,10 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
                      t->phase_ms[0] - ph0[0], t->phase_ms[1] - ph0[1], t->phase_ms[2] - ph0[2] + t->phase_ms[5] - ph0[5] + t->phase_ms[6] - ph0[6],
                      t->phase_ms[3] - ph0[3], t->phase_ms[4] - ph0[4], t->kernel_ms - k0,
                      t->phase_ms[5] - ph0[5], t->phase_ms[6] - ph0[6], t->phase_ms[2] - ph0[2]);
+        std::fprintf(stderr, "[mipx_tree]   popped so far by age in steps: 1:%lld 2:%lld 3:%lld 4:%lld 5:%lld 6:%lld 7+:%lld  mean depth %.1f\n",
+                     (long long)t->age_hist[1], (long long)t->age_hist[2], (long long)t->age_hist[3], (long long)t->age_hist[4],
+                     (long long)t->age_hist[5], (long long)t->age_hist[6], (long long)t->age_hist[7],
+                     (double)t->depth_sum / (double)std::max<int64_t>(1, t->age_hist[1] + t->age_hist[2] + t->age_hist[3] + t->age_hist[4] + t->age_hist[5] + t->age_hist[6] + t->age_hist[7] + t->age_hist[0]));
         std::fprintf(stderr, "[mipx_tree]   probes: read-back %.2f  enqueue %.2f  wait %.2f  results %.2f\n",
                      t->probe_ms[0] - pr0[0], t->probe_ms[1] - pr0[1], t->probe_ms[2] - pr0[2], t->probe_ms[3] - pr0[3]);
     }
