@@ -62,6 +62,8 @@ def main():
     ap.add_argument('--exchange-every', type=int, default=5, help='steps between all-reduces (N > 1)')
     ap.add_argument('--dive', type=int, default=1, choices=[0, 1],
                     help='1: one-level plunge on the register tableau (mipx_tree_set_dive)')
+    ap.add_argument('--reanchor', type=int, default=1, choices=[0, 1],
+                    help='1: after sharding every open node gets an anchor of its own (mipx_tree_reanchor)')
     ap.add_argument('--no-anchor', action='store_true',
                     help='refactor every node from the slack basis instead of the root tableau')
     args = ap.parse_args()
@@ -111,6 +113,8 @@ def main():
         assert st['status'] == 4, f'tree finished during ramp-up: {st}'
     ramp = dict(st)
     tree.keep_shard(rank, world)
+    if args.reanchor and not args.no_anchor:
+        tree.reanchor(tree.stats()['open_nodes'])
     pex = PipelinedExchange(dist, device, n, n_counters=1)
     pex.start(*tree.pseudo_cost_arrays())  # identical on every rank after the replicated ramp-up
 
@@ -135,7 +139,11 @@ def main():
         from oracle import oracle as O
         from concurrent.futures import ThreadPoolExecutor
         threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-        L, U, V, _ = tree.peek_open(4 * B * (3 if threads > 4 else 1))
+        peek = 4 * B * (3 if threads > 4 else 1)
+        L, U, V, _ = tree.peek_open(peek)
+        # the GPU path's anchors (one per re-anchored ancestor), read back for the CPU port
+        atab = tree.anchor_table() if args.reanchor and not args.no_anchor else None
+        asel = tree.peek_anchors(peek) if atab is not None else None
         chunk = 128
         nchunks = (len(L) + chunk - 1) // chunk
         deadline = time.perf_counter() + args.cpu_seconds
@@ -151,9 +159,15 @@ def main():
             e0 = min((ci + 1) * chunk, len(L))
             if args.dive:  # like the GPU path: node + one child continued on the node's tableau
                 r = O.lp_solve_dive_batch(A, b, c, L[ci * chunk:e0], U[ci * chunk:e0], V[ci * chunk:e0], 1,
-                                          ints, pc_tab[0], pc_tab[1], pc_has, cutoff)
+                                          ints, pc_tab[0], pc_tab[1], pc_has, cutoff, anchor_table=atab,
+                                          anchor_sel=None if asel is None else asel[ci * chunk:e0])
                 return e0 - ci * chunk + int((r['dive_var'] >= 0).sum())
-            O.lp_solve_batch(A, b, c, L[ci * chunk:e0], U[ci * chunk:e0], V[ci * chunk:e0])
+            if atab is not None:  # rule -1: no dive, anchors from the table
+                O.lp_solve_dive_batch(A, b, c, L[ci * chunk:e0], U[ci * chunk:e0], V[ci * chunk:e0], -1,
+                                      ints, pc_tab[0], pc_tab[1], pc_has, cutoff, anchor_table=atab,
+                                      anchor_sel=asel[ci * chunk:e0])
+            else:
+                O.lp_solve_batch(A, b, c, L[ci * chunk:e0], U[ci * chunk:e0], V[ci * chunk:e0])
             return e0 - ci * chunk
 
         # like the GPU path, warm starts refactor from the root's optimal tableau when anchoring is on
@@ -180,7 +194,7 @@ def main():
         cpu = {'value': done / t_cpu, 'unit': 'node LP-relaxations/s', 'cores': threads, 'kind': 'port',
                'sample': f'{done} node LPs = {passes} pass(es) over {len(L)} open nodes of the same tree{" and their dive children" if args.dive else ""} (the LPs the GPU solves next: bounds + '
                          f'warm-start bases read back from the device pool), oracle/libmipx_oracle.so '
-                         f'({"anchored at the root tableau like the GPU path" if not args.no_anchor else "slack-basis refactorisation"}), '
+                         f'({("anchored like the GPU path: the tableau of the re-anchored ancestor, read back from the device" if atab is not None else "anchored at the root tableau like the GPU path") if not args.no_anchor else "slack-basis refactorisation"}), '
                          f'{threads} threads over nodes, {t_cpu:.1f} s wall; host: {os.cpu_count()} logical '
                          f'CPUs, {model}'}
 
@@ -274,9 +288,10 @@ def main():
                 'workload': f'C3: {n} vars x {m} rows random dense MILP (BASELINE.md sec. 4, seed '
                             f'{args.seed}), PseudoCostBranchNode, best-first, strong_branch_iters=5, '
                             f'gomory_cuts=False, native frontier engine, {B} open nodes per step per GPU'
+                            + (', every open node re-anchored after sharding' if args.reanchor and not args.no_anchor else '')
                             + (' + one-level dive (each node and, where the rule needs no probes, one child on the same register tableau)' if args.dive else ''),
                 'frontier_batch_per_gpu': B, 'kernel': _ffi.kernel_name(m, n),
-                'anchored_refactorisation': not args.no_anchor, 'dive': bool(args.dive),
+                'anchored_refactorisation': not args.no_anchor, 'reanchored_after_sharding': bool(args.reanchor and not args.no_anchor), 'dive': bool(args.dive),
                 'dive_children_per_step': d['dives'] / args.steps,
                 'mean_pivots_per_lp': d['pivots'] / max(1, d['lp_solved']),
                 'sb_probes_per_s': sums[1] / elapsed,

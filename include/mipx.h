@@ -242,6 +242,19 @@ int mipx_tree_pseudo_costs(mipx_tree *t, double *cost_l, double *cost_r, int32_t
  * (PseudoCostBranchNode.pseudo_costs shared through _kwargs, branch/pseudo_cost.py:38-43). */
 int mipx_tree_set_pseudo_costs(mipx_tree *t, const double *cost_l, const double *cost_r,
                                const int32_t *times_l, const int32_t *times_r);
+/* Re-anchoring (anchor mode, register-tile shapes): the first max_nodes open nodes in queue order
+ * each get an anchor of their own -- the tableau of their warm-start basis -- which their
+ * descendants inherit, so that warm starts refactor over the few pivots that separate a node from
+ * that ancestor instead of the many that separate it from the root.  All other open nodes return
+ * to the root's anchor; an earlier table is released.  max_nodes anchors take
+ * max_nodes * 8 * m * n bytes of HBM (8192 at 256 x 128: 2.1 GB).  No reference counterpart. */
+int mipx_tree_reanchor(mipx_tree *t, int64_t max_nodes);
+/* For the CPU baseline and the parity tests: the anchor-table entry of every open node, in the
+ * order of mipx_tree_peek_open (-1: the root's anchor), and the table itself copied to HOST buffers
+ * (T: count x m x n, vec: count x (n + 3m), idx: count x (2n + m); any may be NULL).  Both return
+ * a count. */
+int64_t mipx_tree_peek_anchors(mipx_tree *t, int64_t max_nodes, int32_t *anchor);
+int64_t mipx_tree_anchor_table(mipx_tree *t, double *T, double *vec, int32_t *idx);
 /* Throughput option for frontier batches > 1 (register-tile shapes): the workgroup that solved a
  * node branches in place when the rule can decide without probes (see mipx_lp_dive_batch) and
  * solves one child on the tableau it holds; that child is evaluated in the same step (its sibling

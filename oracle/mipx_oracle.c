@@ -157,8 +157,10 @@ static int lp_solve_impl(int m, int n, const double *A, const double *b, const d
                          const double *l_in, const double *u_in, const int8_t *vstat_in, int max_iter,
                          int32_t *status_out, double *obj_out, double *x_out, double *y_out,
                          double *dj_out, int8_t *vstat_out, int32_t *iters_out,
-                         int32_t *npivots_out, const mipx_dive_t *dv) {
+                         int32_t *npivots_out, const mipx_dive_t *dv, const double *aT,
+                         const double *avec, const int32_t *aidx) {
     if (m < 0 || n <= 0) return -1;
+    if (!aT) { aT = g_anchor_T; avec = g_anchor_vec; aidx = g_anchor_idx; }  /* (set_anchor: one for all) */
     /* the dive moves a bound: work on copies */
     double *l = (double *)malloc(sizeof(double) * (size_t)n);
     double *u = (double *)malloc(sizeof(double) * (size_t)n);
@@ -184,10 +186,10 @@ static int lp_solve_impl(int m, int n, const double *A, const double *b, const d
     double *va = (double *)malloc(sizeof(double) * (size_t)n);
     double *vb = (double *)malloc(sizeof(double) * (size_t)n);
 
-    if (g_anchor_T && vstat_in) {
-        memcpy(t.T, g_anchor_T, sizeof(double) * (size_t)m * n);
-        for (int j = 0; j < n; j++) { t.d[j] = g_anchor_vec[j]; t.nvar[j] = g_anchor_idx[j]; }
-        for (int i = 0; i < m; i++) { t.beta0[i] = g_anchor_vec[n + i]; t.bvar[i] = g_anchor_idx[n + i]; }
+    if (aT && vstat_in) {
+        memcpy(t.T, aT, sizeof(double) * (size_t)m * n);
+        for (int j = 0; j < n; j++) { t.d[j] = avec[j]; t.nvar[j] = aidx[j]; }
+        for (int i = 0; i < m; i++) { t.beta0[i] = avec[n + i]; t.bvar[i] = aidx[n + i]; }
     } else {
         for (int i = 0; i < m; i++) {
             for (int j = 0; j < n; j++) t.T[(size_t)i * n + j] = -A[(size_t)i * n + j];
@@ -466,7 +468,7 @@ int mipx_oracle_lp_solve(int m, int n, const double *A, const double *b, const d
                          double *dj_out, int8_t *vstat_out, int32_t *iters_out,
                          int32_t *npivots_out) {
     return lp_solve_impl(m, n, A, b, c, l, u, vstat_in, max_iter, status_out, obj_out, x_out, y_out, dj_out,
-                         vstat_out, iters_out, npivots_out, NULL);
+                         vstat_out, iters_out, npivots_out, NULL, NULL, NULL, NULL);
 }
 
 /* one node LP with the in-place dive (outputs of the child through dv) */
@@ -476,7 +478,7 @@ int mipx_oracle_lp_solve_dive(int m, int n, const double *A, const double *b, co
                               int8_t *vstat_out, int32_t *iters_out, int32_t *npivots_out,
                               const mipx_dive_t *dv) {
     return lp_solve_impl(m, n, A, b, c, l, u, vstat_in, max_iter, status_out, obj_out, x_out, NULL, NULL,
-                         vstat_out, iters_out, npivots_out, dv);
+                         vstat_out, iters_out, npivots_out, dv, NULL, NULL, NULL);
 }
 
 /* batch with the dive: every output array has 2 * batch rows (the nodes, then their dive children;
@@ -488,7 +490,10 @@ int mipx_oracle_lp_solve_dive_batch(int m, int n, const double *A, const double 
                                     const uint8_t *has_entry, double cutoff, int32_t *status,
                                     double *obj, double *x, int8_t *vstat_out, int32_t *iters,
                                     int32_t *npivots, int32_t *dive_var, int32_t *dive_dir,
-                                    double *dive_val) {
+                                    double *dive_val, const double *atab_T, const double *atab_vec,
+                                    const int32_t *atab_idx, const int32_t *anchor_sel) {
+    /* optional anchor table (mipx_tree_reanchor): node k starts from entry anchor_sel[k], entries
+     * m*n / n+3m / 2n+m apart; -1 or no table: the anchor set by mipx_oracle_set_anchor */
     const size_t nv = (size_t)n + m;
     for (int k = 0; k < batch; k++) {
         const size_t ck = (size_t)batch + k;
@@ -503,7 +508,10 @@ int mipx_oracle_lp_solve_dive_batch(int m, int n, const double *A, const double 
                                vstat_in ? vstat_in + (size_t)k * nv : NULL, max_iter, status + k,
                                obj ? obj + k : NULL, x ? x + (size_t)k * n : NULL, NULL, NULL,
                                vstat_out ? vstat_out + (size_t)k * nv : NULL, iters ? iters + k : NULL,
-                               npivots ? npivots + k : NULL, &dv);
+                               npivots ? npivots + k : NULL, rule >= 0 ? &dv : NULL,
+                               (atab_T && anchor_sel && anchor_sel[k] >= 0) ? atab_T + (size_t)anchor_sel[k] * m * n : NULL,
+                               (atab_T && anchor_sel && anchor_sel[k] >= 0) ? atab_vec + (size_t)anchor_sel[k] * (n + 3 * (size_t)m) : NULL,
+                               (atab_T && anchor_sel && anchor_sel[k] >= 0) ? atab_idx + (size_t)anchor_sel[k] * (2 * (size_t)n + m) : NULL);
         if (rc) return rc;
     }
     return 0;

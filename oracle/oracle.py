@@ -79,7 +79,7 @@ class _Dive(C.Structure):
 
 
 def lp_solve_dive_batch(A, b, c, l, u, vstat, rule, int_idx, cost_l, cost_r, has_entry, cutoff,
-                        max_iter=0):
+                        max_iter=0, anchor_table=None, anchor_sel=None):
     """Node LPs with the in-place dive (LpArgs::dive of the GPU kernel): every array of the result
     has 2 * batch rows -- the nodes, then their dive children (status -1 where none was solved) --
     plus dive_var (-1: no dive), dive_dir, dive_val per node."""
@@ -104,7 +104,11 @@ def lp_solve_dive_batch(A, b, c, l, u, vstat, rule, int_idx, cost_l, cost_r, has
         _p(vstat, _i8p), C.c_int(int(max_iter)), C.c_int(int(rule)), C.c_int(len(ii)), _p(ii, _i32p),
         _p(cl, _dp), _p(cr, _dp), he.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_double(float(cutoff)),
         _p(status, _i32p), _p(obj, _dp), _p(x, _dp), _p(vout, _i8p), _p(iters, _i32p), _p(npiv, _i32p),
-        _p(dvar, _i32p), _p(ddir, _i32p), _p(dval, _dp))
+        _p(dvar, _i32p), _p(ddir, _i32p), _p(dval, _dp),
+        None if anchor_table is None else _p(anchor_table[0], _dp),
+        None if anchor_table is None else _p(anchor_table[1], _dp),
+        None if anchor_table is None else _p(anchor_table[2], _i32p),
+        None if anchor_sel is None else _p(np.ascontiguousarray(anchor_sel, np.int32), _i32p))
     assert rc == 0, f'oracle lp_solve_dive_batch failed rc={rc}'
     return dict(status=status, obj=obj, x=x, vstat=vout, iters=iters, npivots=npiv, dive_var=dvar,
                 dive_dir=ddir, dive_val=dval)

@@ -25,7 +25,8 @@ SYMBOLS = [
     'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
     'mipx_tree_solution', 'mipx_tree_set_primal_bound', 'mipx_tree_pseudo_costs', 'mipx_tree_set_pseudo_costs',
     'mipx_tree_set_trace', 'mipx_tree_trace', 'mipx_tree_peek_open', 'mipx_tree_keep_shard',
-    'mipx_tree_set_step_hook', 'mipx_lp_dive_batch', 'mipx_tree_set_dive',
+    'mipx_tree_set_step_hook', 'mipx_lp_dive_batch', 'mipx_tree_set_dive', 'mipx_tree_reanchor',
+    'mipx_tree_peek_anchors', 'mipx_tree_anchor_table',
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -363,6 +364,38 @@ class Tree:
             raise err
         self.problem.ctx.check(rc, 'mipx_tree_solve')
         return st.as_dict()
+
+    def reanchor(self, max_nodes):
+        """Give the first max_nodes open nodes an anchor of their own (mipx_tree_reanchor)."""
+        L = lib()
+        L.mipx_tree_reanchor.argtypes = [_vp, C.c_int64]
+        self.problem.ctx.check(L.mipx_tree_reanchor(self._h, int(max_nodes)), 'mipx_tree_reanchor')
+
+    def peek_anchors(self, max_nodes):
+        """Anchor-table entry of each open node, in the order of peek_open (-1: the root's anchor)."""
+        a = np.full(int(max_nodes), -1, np.int32)
+        L = lib()
+        L.mipx_tree_peek_anchors.argtypes = [_vp, C.c_int64, _vp]
+        L.mipx_tree_peek_anchors.restype = C.c_int64
+        k = L.mipx_tree_peek_anchors(self._h, int(max_nodes), _ptr(a))
+        if k < 0:
+            self.problem.ctx.check(int(k), 'mipx_tree_peek_anchors')
+        return a[:k]
+
+    def anchor_table(self):
+        """(T, vec, idx) of the re-anchoring table as host arrays, or None."""
+        L = lib()
+        L.mipx_tree_anchor_table.argtypes = [_vp, _vp, _vp, _vp]
+        L.mipx_tree_anchor_table.restype = C.c_int64
+        K = L.mipx_tree_anchor_table(self._h, None, None, None)
+        if K <= 0:
+            return None
+        n, m = self.problem.n, self.problem.m
+        T = np.zeros((K, m, n)); vec = np.zeros((K, n + 3 * m)); idx = np.zeros((K, 2 * n + m), np.int32)
+        k = L.mipx_tree_anchor_table(self._h, _ptr(T), _ptr(vec), _ptr(idx))
+        if k < 0:
+            self.problem.ctx.check(int(k), 'mipx_tree_anchor_table')
+        return T, vec, idx
 
     def set_dive(self, on=True):
         """One-level plunge on the register tableau (mipx_tree_set_dive)."""

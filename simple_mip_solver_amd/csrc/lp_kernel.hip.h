@@ -49,6 +49,12 @@ struct LpArgs {
     // instead of from the slack basis (fewer pivots when the bases are close, e.g. the root's)
     const double *anchor_T, *anchor_vec;
     const int32_t *anchor_idx;
+    // optional table of anchors (frontier engine): node k starts from entry anchor_sel[row of k in
+    // the node pool] of the table (same layout per entry, entries m*n / n+3m / 2n+m apart), or from
+    // the single anchor above where the entry is -1.  Register kernels only.
+    const int32_t *anchor_sel = nullptr;
+    const double *atab_T = nullptr, *atab_vec = nullptr;
+    const int32_t *atab_idx = nullptr;
     int refactor_only;             // stop after the refactorisation (used to build an anchor)
     int max_iter;
     int32_t *status;
@@ -628,7 +634,11 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     const int8_t *vin = g.vstat_in ? g.vstat_in + src * nv : nullptr;
 
     // ---- 0. T = -A, beta0 = -b, d = c, slack basis (or the anchor's tableau state) -----------
-    const bool anchored = g.anchor_T != nullptr && vin != nullptr;
+    const int asel = (g.anchor_sel != nullptr && vin != nullptr) ? __builtin_amdgcn_readfirstlane(g.anchor_sel[src]) : -1;
+    const double *aT = asel >= 0 ? g.atab_T + (size_t)asel * ((size_t)m * n) : g.anchor_T;
+    const double *avec = asel >= 0 ? g.atab_vec + (size_t)asel * (size_t)(n + 3 * m) : g.anchor_vec;
+    const int32_t *aidx = asel >= 0 ? g.atab_idx + (size_t)asel * (size_t)(2 * n + m) : g.anchor_idx;
+    const bool anchored = aT != nullptr && vin != nullptr;
     const double sgn = anchored ? 1.0 : -1.0;
 #pragma unroll
     for (int ii = 0; ii < R; ii++) {
@@ -640,7 +650,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         // The tableau first: its 256 KiB stream through the L1 while the border loads below wait
         // for HBM.  Every load is issued unconditionally from a clamped address (512 contiguous
         // bytes per wave instruction); sign and padding are fixed where the values are first used
-        const double *tsrc = anchored ? g.anchor_T : gA;
+        const double *tsrc = anchored ? aT : gA;
         if ((n & 1) == 0 && n >= 2) {  // adjacent column pairs as one 16-byte load
             int poff[C / 2];
 #pragma unroll
@@ -669,10 +679,10 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         // memory latency, not one per array); clamped addresses, the padding is fixed afterwards
         static_assert(NT >= NP + MP, "one staging element per thread");
         const int ic = min(tid, m > 0 ? m - 1 : 0), jc = min(tid, n - 1), vc = min(tid, nv - 1);
-        const double g_b0 = anchored ? g.anchor_vec[n + ic] : (m > 0 ? gb[ic] : 0.0);
-        const int g_bv = anchored ? g.anchor_idx[n + ic] : n + ic;
-        const double g_d = anchored ? g.anchor_vec[jc] : gc[jc];
-        const int g_nv = anchored ? g.anchor_idx[jc] : jc;
+        const double g_b0 = anchored ? avec[n + ic] : (m > 0 ? gb[ic] : 0.0);
+        const int g_bv = anchored ? aidx[n + ic] : n + ic;
+        const double g_d = anchored ? avec[jc] : gc[jc];
+        const int g_nv = anchored ? aidx[jc] : jc;
         const double g_lo = lk[jc], g_up = uk[jc];
         const int8_t g_st = vin ? vin[vc] : (int8_t)0;
         if (tid < MP) {

@@ -177,6 +177,10 @@ struct mipx_tree {
     // device pool + per-step buffers
     double *pool_l = nullptr, *pool_u = nullptr;
     int8_t *pool_v = nullptr;
+    int32_t *pool_a = nullptr;     // anchor-table entry per pool row (-1: the problem's single anchor)
+    double *atab_T = nullptr, *atab_vec = nullptr;   // mipx_tree_reanchor: one anchor per re-anchored node
+    int32_t *atab_idx = nullptr;
+    int64_t atab_count = 0;
     int32_t *d_int_idx = nullptr, *d_pairs = nullptr, *d_pairs2 = nullptr;
     double *d_cost_l = nullptr, *d_cost_r = nullptr, *d_cost_l2 = nullptr, *d_cost_r2 = nullptr;
     uint8_t *d_has = nullptr, *d_has2 = nullptr;
@@ -300,6 +304,9 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
     a.anchor_T = t->prob->anchor_on ? t->prob->anchor_T : nullptr;
     a.anchor_vec = t->prob->anchor_on ? t->prob->anchor_vec : nullptr;
     a.anchor_idx = t->prob->anchor_on ? t->prob->anchor_idx : nullptr;
+    if (slot != nullptr && t->atab_T != nullptr) {  // node LPs: the anchor their record names
+        a.anchor_sel = t->pool_a; a.atab_T = t->atab_T; a.atab_vec = t->atab_vec; a.atab_idx = t->atab_idx;
+    }
     a.refactor_only = 0;
     a.status = status; a.obj = obj; a.x = x; a.y = nullptr; a.vstat_out = vout;
     a.iters = iters; a.npivots = npiv; a.batch = batch;
@@ -714,6 +721,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             ca.x = S.d_x; ca.vstat = S.d_vout;
             ca.dst_l = t->pool_l; ca.dst_u = t->pool_u; ca.dst_v = t->pool_v;
             ca.child_slot = dp + 3 * cnt;
+            ca.src_a = t->pool_a; ca.dst_a = t->pool_a;
             hipLaunchKernelGGL(mipx::make_children, dim3(2 * cnt), dim3(256), 0, cs, ca);
             HIP_TRY(ctx, hipGetLastError());
             return MIPX_OK;
@@ -768,6 +776,8 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     int rc = 0;
     rc |= dmalloc(ctx, &t->pool_l, cap * n); rc |= dmalloc(ctx, &t->pool_u, cap * n);
     rc |= dmalloc(ctx, &t->pool_v, cap * nv);
+    rc |= dmalloc(ctx, &t->pool_a, cap);
+    if (t->pool_a && hipMemset(t->pool_a, 0xff, cap * 4) != hipSuccess) rc |= MIPX_EHIP;
     rc |= dmalloc(ctx, &t->d_int_idx, (size_t)n_int);
     rc |= dmalloc(ctx, &t->d_pairs, 5 * (pc / 2 > 2 * B ? pc / 2 : 2 * B));   // (second half: children of dive children)
     rc |= dmalloc(ctx, &t->d_pairs2, 5 * (pc / 2 > 2 * B ? pc / 2 : 2 * B));
@@ -851,7 +861,7 @@ void mipx_tree_destroy(mipx_tree *t) {
     if (t->ev_child) (void)hipEventDestroy(t->ev_child);
     if (t->h_pairs) (void)hipHostFree(t->h_pairs);
     if (t->h_pres) (void)hipHostFree(t->h_pres);
-    void *ptrs[] = {t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_pairs, t->d_pairs2, t->d_cost_l,
+    void *ptrs[] = {t->pool_a, t->atab_T, t->atab_vec, t->atab_idx, t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_pairs, t->d_pairs2, t->d_cost_l,
                     t->d_cost_r, t->d_has, t->d_cost_l2, t->d_cost_r2, t->d_has2, t->pp_l, t->pp_u, t->pp_v, t->pp_obj, t->pp_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -995,6 +1005,65 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
     return MIPX_OK;
 }
 
+/* Re-anchoring: the first `max_nodes` open nodes in queue order each get an anchor of their own --
+ * the tableau of their warm-start basis, built by one refactor-only launch from the current
+ * anchors -- and their descendants inherit it (their bases stay a few pivots away from it, where
+ * the root's tableau drifts further away with every level).  Every other open node goes back to
+ * the problem's single anchor.  288 GB of HBM hold a million 256 x 128 anchors; 8192 take 2.1 GB. */
+int mipx_tree_reanchor(mipx_tree *t, int64_t max_nodes) {
+    if (!t || max_nodes < 1) return MIPX_EINVAL;
+    mipx_ctx *ctx = t->ctx;
+    if (!t->anchor_mode || !t->anchor_set || pick_cfg(t->m, t->n) == nullptr)
+        return fail(ctx, MIPX_EINVAL, "mipx_tree_reanchor: needs the anchor mode, a solved root and a register-tile shape");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(t->st3));
+    HIP_TRY(ctx, hipStreamSynchronize(t->st2));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int64_t> order;
+    tree_queue_ids(t, order);
+    const int64_t K = std::min<int64_t>(max_nodes, (int64_t)order.size());
+    if (K == 0) return MIPX_OK;
+    const size_t m = t->m, n = t->n;
+    double *nT = nullptr, *nvec = nullptr;
+    int32_t *nidx = nullptr, *d_sl = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&nT, (size_t)K * m * n * 8));
+    HIP_TRY(ctx, hipMalloc((void **)&nvec, (size_t)K * (n + 3 * m) * 8));
+    HIP_TRY(ctx, hipMalloc((void **)&nidx, (size_t)K * (2 * n + m) * 4));
+    HIP_TRY(ctx, hipMalloc((void **)&d_sl, (size_t)K * 4));
+    std::vector<int32_t> sl((size_t)K);
+    for (int64_t k = 0; k < K; k++) sl[(size_t)k] = t->nodes[order[(size_t)k]].slot;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(d_sl, sl.data(), (size_t)K * 4, hipMemcpyHostToDevice, st));
+    // refactor-only solves of the K nodes (from the anchors they have now), every final tableau dumped
+    mipx::LpArgs a;
+    a.m = t->m; a.n = t->n;
+    a.A = t->prob->dA; a.b = t->prob->db; a.c = t->prob->dc;
+    a.A_stride = a.b_stride = a.c_stride = 0;
+    a.l = t->pool_l; a.u = t->pool_u; a.vstat_in = t->pool_v; a.slot = d_sl; a.max_iter = 0;
+    a.anchor_T = t->prob->anchor_on ? t->prob->anchor_T : nullptr;
+    a.anchor_vec = t->prob->anchor_on ? t->prob->anchor_vec : nullptr;
+    a.anchor_idx = t->prob->anchor_on ? t->prob->anchor_idx : nullptr;
+    if (t->atab_T != nullptr) { a.anchor_sel = t->pool_a; a.atab_T = t->atab_T; a.atab_vec = t->atab_vec; a.atab_idx = t->atab_idx; }
+    a.refactor_only = 1;
+    a.status = nullptr; a.obj = nullptr; a.x = nullptr; a.y = nullptr; a.vstat_out = nullptr;
+    a.iters = nullptr; a.npivots = nullptr; a.batch = (int)K;
+    a.dbg_T = nT; a.dbg_vec = nvec; a.dbg_idx = nidx; a.dbg_all = 1;
+    int rc = launch_lp_any(t->prob, a, (int)K, st);
+    if (rc == MIPX_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, MIPX_EHIP, "mipx_tree_reanchor: launch failed");
+    if (rc == MIPX_OK) {
+        // the old table goes away: every row back to the single anchor, then the K new entries
+        const size_t cap = (size_t)t->capacity;
+        if (hipMemsetAsync(t->pool_a, 0xff, cap * 4, st) != hipSuccess) rc = MIPX_EHIP;
+        hipLaunchKernelGGL(mipx::set_anchor_ids, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, d_sl, (int)K, t->pool_a);
+        if (hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, MIPX_EHIP, "mipx_tree_reanchor: scatter failed");
+    }
+    (void)hipFree(d_sl);
+    if (rc != MIPX_OK) { (void)hipFree(nT); (void)hipFree(nvec); (void)hipFree(nidx); return rc; }
+    if (t->atab_T) { (void)hipFree(t->atab_T); (void)hipFree(t->atab_vec); (void)hipFree(t->atab_idx); }
+    t->atab_T = nT; t->atab_vec = nvec; t->atab_idx = nidx; t->atab_count = K;
+    return MIPX_OK;
+}
+
 int mipx_tree_set_dive(mipx_tree *t, int on) {
     if (!t) return MIPX_EINVAL;
     if (on && t->max_batch == 1)
@@ -1085,6 +1154,34 @@ int64_t mipx_tree_peek_open(mipx_tree *t, int64_t max_nodes, double *l, double *
         if (dual_bound) dual_bound[k] = nd.dual_bound;
     }
     return k;
+}
+
+/* Anchor-table entries of the open nodes, in the order of mipx_tree_peek_open (-1: the single anchor). */
+int64_t mipx_tree_peek_anchors(mipx_tree *t, int64_t max_nodes, int32_t *anchor) {
+    if (!t || max_nodes < 0 || !anchor) return MIPX_EINVAL;
+    if (hipStreamSynchronize(t->ctx->stream) != hipSuccess || hipStreamSynchronize(t->st3) != hipSuccess) return MIPX_EHIP;
+    std::vector<int64_t> order;
+    tree_queue_ids(t, order);
+    const size_t cap = (size_t)t->capacity;
+    std::vector<int32_t> all(cap);
+    if (hipMemcpy(all.data(), t->pool_a, cap * 4, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
+    int64_t k = 0;
+    for (size_t pos = 0; pos < order.size() && k < max_nodes; pos++, k++)
+        anchor[k] = t->atab_T ? all[(size_t)t->nodes[order[pos]].slot] : -1;
+    return k;
+}
+
+/* The anchor table of mipx_tree_reanchor: returns the number of entries; copies them to HOST buffers
+ * where given (T: count x m x n, vec: count x (n + 3m), idx: count x (2n + m)). */
+int64_t mipx_tree_anchor_table(mipx_tree *t, double *T, double *vec, int32_t *idx) {
+    if (!t) return MIPX_EINVAL;
+    const size_t K = (size_t)t->atab_count, m = t->m, n = t->n;
+    if (K == 0 || !t->atab_T) return 0;
+    if (hipStreamSynchronize(t->ctx->stream) != hipSuccess) return MIPX_EHIP;
+    if (T && hipMemcpy(T, t->atab_T, K * m * n * 8, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
+    if (vec && hipMemcpy(vec, t->atab_vec, K * (n + 3 * m) * 8, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
+    if (idx && hipMemcpy(idx, t->atab_idx, K * (2 * n + m) * 4, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
+    return (int64_t)K;
 }
 
 /* Multi-GPU sharding: after a replicated, deterministic ramp-up every rank

@@ -305,3 +305,67 @@ def test_full_node_pool_stops_the_search_cleanly():
     with pytest.warns(RuntimeWarning, match='node pool is full'):
         bb.solve()
     assert bb.status == 'stopped on iterations or time'
+
+
+def test_reanchored_step_matches_the_oracle(oracle):
+    """mipx_tree_reanchor: open nodes get the tableau of their warm-start basis as their own anchor.
+    The table is what the oracle builds for the same bases (refactor-only from the root's tableau), a
+    warm start from one's own anchor needs no refactorisation pivot, and one engine step over all
+    open nodes does exactly the pivots the oracle does on them with the same table."""
+    from simple_mip_solver_amd import _ffi
+    ctx = _ffi.default_context()
+    n, m, MB, K = 64, 32, 1024, 200
+    A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=0)
+    prob = _ffi.Problem(ctx, A, b, c)
+
+    def ramp():
+        t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=MB, pool_capacity=1 << 15)
+        t.set_anchor_mode(True)
+        t.set_dive(True)
+        st = t.stats()
+        while st['open_nodes'] < 300:
+            st = t.solve(mip_gap=0.0, frontier_batch=32, max_steps=1)
+        return t, st
+    t, st0 = ramp()
+    N = st0['open_nodes']
+    assert N < MB and st0['primal_bound'] == float('inf')
+    with pytest.raises(_ffi.MipxError, match='MIPX_EINVAL'):
+        t.reanchor(0)
+    assert t.anchor_table() is None and np.all(t.peek_anchors(10) == -1)
+    t.reanchor(K)                           # the first K open nodes; the others keep the root's anchor
+    L, U, V, _ = t.peek_open(10 ** 6)
+    sel = t.peek_anchors(10 ** 6)
+    T, vec, idx = t.anchor_table()
+    assert len(L) == N and len(T) == K and list(sel[:K]) == list(range(K)) and np.all(sel[K:] == -1)
+    root = oracle.lp_solve(A, b, c, l, u)
+    root_anchor = oracle.make_anchor(A, b, c, root['vstat'])
+    with oracle.anchored(root_anchor):
+        for k in (0, 1, K // 2, K - 1):     # a table entry is the oracle's tableau of that basis, bit for bit
+            mine = oracle.make_anchor(A, b, c, V[k])
+            assert np.array_equal(mine['T'], T[k]) and np.array_equal(mine['idx'][:n + m], idx[k][:n + m])
+            assert np.array_equal(mine['vec'][:n + m], vec[k][:n + m])
+    # one step over all N open nodes; the oracle on the same nodes, table and pseudo costs
+    cl, cr, tl, tr = t.pseudo_cost_arrays()
+    has = ((tl > 0) | (tr > 0)).astype(np.uint8)
+    with oracle.anchored(root_anchor):
+        o = oracle.lp_solve_dive_batch(A, b, c, L, U, V, 1, ints, cl, cr, has, float('inf'),
+                                       anchor_table=(T, vec, idx), anchor_sel=sel)
+    assert np.array_equal(o['npivots'][:K], o['iters'][:K])       # own anchor: no refactorisation at all
+    assert np.any(o['npivots'][K:N] > o['iters'][K:N])            # from the root's anchor: some
+    before = t.stats()
+    after = t.solve(mip_gap=0.0, frontier_batch=MB, max_steps=1)
+    dives = after['dives'] - before['dives']
+    assert after['lp_solved'] - before['lp_solved'] == N + dives and dives <= int((o['dive_var'] >= 0).sum())
+    # (the engine drops dive children that need strong-branching probes of their own: the pivots of
+    # the nodes themselves are exact, those of the kept children bounded both ways)
+    parents = int(o['npivots'][:N].sum())
+    kids = np.sort(o['npivots'][N:][o['dive_var'] >= 0])
+    got = after['pivots'] - before['pivots']
+    assert parents + int(kids[:dives].sum()) <= got <= parents + int(kids[len(kids) - dives:].sum())
+    # descendants inherit their ancestor's entry; the search itself is unchanged by the anchors
+    assert (t.peek_anchors(10 ** 6) >= 0).sum() >= K
+    t2, _ = ramp()
+    t2.solve(mip_gap=0.0, frontier_batch=MB, max_steps=1)
+    a, b2 = (x.solve(mip_gap=0.0, frontier_batch=256, max_steps=6) for x in (t, t2))
+    assert a['evaluated_nodes'] == b2['evaluated_nodes'] and isclose(a['dual_bound'], b2['dual_bound'], abs_tol=1e-7)
+    assert a['pivots'] < b2['pivots']
