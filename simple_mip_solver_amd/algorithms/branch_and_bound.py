@@ -122,7 +122,7 @@ class BranchAndBound(BaseAlgorithm):
 
     def __init__(self, model, Node=BaseNode, node_queue=None, node_limit=INF, mip_gap=.0001,
                  logging=False, max_run_time=INF, initial_primal_bound=INF, frontier_batch=None,
-                 pool_capacity=1 << 16, **kwargs):
+                 pool_capacity=1 << 16, anchor=None, dive=None, **kwargs):
         """All problems are converted to minimisation with A x >= b on the way in.  **kwargs are
         handed to every bound()/branch() call and refreshed from what those calls return
         (e.g. pseudo_costs={}, strong_branch_iters=5, gomory_cuts=False).
@@ -131,7 +131,11 @@ class BranchAndBound(BaseAlgorithm):
         loop): run the whole search in the native frontier engine (mipx_tree_*), evaluating that
         many open nodes per GPU step with node records resident in HBM.  Only for the stock node
         classes, the default queue and gomory_cuts=False; frontier_batch=1 keeps the reference's
-        exact node order.  In this mode `tree` holds only the root (nodes live on the device)."""
+        exact node order.  In this mode `tree` holds only the root (nodes live on the device).
+        anchor / dive (default: on for frontier_batch > 1, register-tile shapes): warm starts
+        refactor from the root's optimal tableau instead of the slack basis; the workgroup that
+        solved a node also solves one child on the tableau it holds (same optimum, another node
+        order -- see DESIGN.md section 4)."""
         self._native = None
         self._native_stats = None
         if frontier_batch is not None:
@@ -143,6 +147,10 @@ class BranchAndBound(BaseAlgorithm):
             assert kwargs.get('gomory_cuts') is False, \
                 'frontier_batch needs gomory_cuts=False (cut rounds run on the per-node path)'
         self.frontier_batch = frontier_batch
+        batched = frontier_batch is not None and frontier_batch > 1
+        self._anchor = batched if anchor is None else bool(anchor)
+        self._dive = batched if dive is None else bool(dive)
+        assert not (self._dive and not batched), 'dive needs frontier_batch > 1'
         self._pool_capacity = pool_capacity
         node_queue = node_queue or PriorityQueue()
         super().__init__(model=model, Node=Node, node_attributes=self._node_attributes,
@@ -248,6 +256,10 @@ class BranchAndBound(BaseAlgorithm):
                 max_batch=self.frontier_batch, pool_capacity=self._pool_capacity)
             if self.primal_bound < INF:
                 self._native.set_primal_bound(self.primal_bound)
+            if self._anchor:
+                self._native.set_anchor_mode(True)
+            if self._dive:
+                self._native.set_dive(True)
         st = self._native.solve(node_limit=0 if self.node_limit == INF else self.node_limit,
                                 mip_gap=self.mip_gap,
                                 max_seconds=0.0 if self.max_run_time == INF else self.max_run_time,

@@ -369,3 +369,20 @@ def test_reanchored_step_matches_the_oracle(oracle):
     a, b2 = (x.solve(mip_gap=0.0, frontier_batch=256, max_steps=6) for x in (t, t2))
     assert a['evaluated_nodes'] == b2['evaluated_nodes'] and isclose(a['dual_bound'], b2['dual_bound'], abs_tol=1e-7)
     assert a['pivots'] < b2['pivots']
+
+
+def test_driver_options_for_the_native_mode():
+    """BranchAndBound(frontier_batch > 1) turns the anchor and the dive on by default; both can be
+    switched off; the exact mode has neither."""
+    make = lambda: random_model(30, 12, 3)
+    ref = BranchAndBound(make(), PseudoCostBranchNode, pseudo_costs={}, gomory_cuts=False, frontier_batch=1)
+    ref.solve()
+    assert ref._native_stats['dives'] == 0
+    for kw in ({}, {'dive': False}, {'anchor': False}, {'anchor': False, 'dive': False}):
+        bb = BranchAndBound(make(), PseudoCostBranchNode, pseudo_costs={}, gomory_cuts=False, frontier_batch=64,
+                            pool_capacity=1 << 15, **kw)
+        bb.solve()
+        assert bb.status == 'optimal' and isclose(bb.objective_value, ref.objective_value, abs_tol=1e-6)
+        assert (bb._native_stats['dives'] > 0) == kw.get('dive', True)
+    with pytest.raises(AssertionError, match='dive needs frontier_batch > 1'):
+        BranchAndBound(make(), gomory_cuts=False, frontier_batch=1, dive=True)
