@@ -43,6 +43,20 @@
  *   4. status 0 optimal / 1 primal infeasible / 2 unbounded (optimum depends on M) /
  *      3 iteration limit -- the Clp codes the reference reads (base_node.py:274-275,
  *      pseudo_cost.py:86).
+ *   Options the frontier engine uses, restated here for the parity tests:
+ *   A. anchored refactorisation: step 0 may start from the stored tableau of another basis of the
+ *      same rows (one for all: mipx_oracle_set_anchor; or one per node from a table:
+ *      mipx_oracle_lp_solve_dive_batch) instead of the slack basis; step 1 then pivots in every
+ *      variable wanted basic that is nonbasic there (ascending), on the row of largest |T_iq| among
+ *      rows whose variable is not wanted basic (fallback: wanted, not pivoted in by this
+ *      refactorisation).
+ *   B. in-place dive (mipx_oracle_lp_solve_dive): after an optimal, fractional node LP below the
+ *      cutoff the branching rule (most fractional, base_node.py:544-562; or pseudo costs,
+ *      pseudo_cost.py:118-133, only if every fractional variable has an entry; ties -> earliest
+ *      in the integer list) picks a variable; if it is basic one of its bounds moves (the child of
+ *      base_node.py:592-608: left u_j = floor(x_j) if cost_l (x_j - floor) <= cost_r (ceil - x_j),
+ *      else right l_j = ceil(x_j); most fractional: the nearer side, ties left) and step 3
+ *      continues on the tableau at hand with fresh iteration / anti-cycling counters.
  */
 #include <math.h>
 #include <stdint.h>
