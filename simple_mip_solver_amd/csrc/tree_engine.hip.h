@@ -118,6 +118,11 @@ struct BucketQueue {
                 want -= v.size();
                 count -= v.size();
                 v.clear();
+            } else if (v.size() > 8 * want && tab.size() * 16 < kMaxBuckets && refinements < max_refinements) {
+                // a deep search piles its open nodes just above the dual bound: buckets sized for
+                // the first key end up holding 10^5..10^6 of them and every step pays nth_element
+                // and an erase over all of those (2.7 ms per step at 5 M open nodes) -> finer buckets
+                refine();
             } else {
                 auto less = [](const Item &a, const Item &b) { return a.key < b.key || (a.key == b.key && a.id < b.id); };
                 std::nth_element(v.begin(), v.begin() + (std::ptrdiff_t)want, v.end(), less);
@@ -128,6 +133,20 @@ struct BucketQueue {
             }
         }
     }
+    int refinements = 0;
+    // (two refinements = 256 x finer than the first scale: beyond that the pushes of a step scatter
+    // over 10^5 bucket tails and the bookkeeping pays in cache misses what the pop saves)
+    int max_refinements = std::getenv("MIPX_BQ_REFINE") ? std::atoi(std::getenv("MIPX_BQ_REFINE")) : 2;
+    void refine() {  // 16 x finer buckets, same order of the items inside the new buckets' sources
+        std::vector<std::vector<Item>> old;
+        old.swap(tab);
+        inv_width *= 16.0;
+        count = 0;
+        cur = 0;
+        refinements++;
+        for (const auto &v : old)
+            for (const Item &it : v) push(it.key, it.id);
+    }
     // every item, in bucket order (for peek / sharding)
     void items(std::vector<Item> &out) const {
         for (size_t i = cur; i < tab.size(); i++) out.insert(out.end(), tab[i].begin(), tab[i].end());
@@ -137,6 +156,7 @@ struct BucketQueue {
         count = 0;
         cur = 0;
     }
+    // (the bucket scale -- k0, width, refinements -- survives a clear: keep_shard refills the queue)
 };
 
 // Per-step device outputs and host staging, double-buffered so that the host bookkeeping of step
@@ -256,10 +276,11 @@ double tree_dual_bound(mipx_tree *t) { return std::fmin(tree_open_min(t), t->clo
 // reference current_gap (branch_and_bound.py:203-213); -1 encodes None
 double tree_gap(mipx_tree *t) {
     const double inf = std::numeric_limits<double>::infinity();
-    const double p = t->primal, d = tree_dual_bound(t);
+    const double p = t->primal;
+    if (p == inf) return -1.0;  // (before the dual bound: that one scans a bucket of the open list)
+    const double d = tree_dual_bound(t);
     if (p == 0 && d == 0) return 0.0;
     if (p == 0) return inf;
-    if (p == inf) return -1.0;
     return std::fabs(p - d) / std::fabs(p);
 }
 
@@ -843,6 +864,7 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     root.dual_bound = -std::numeric_limits<double>::infinity();
     root.depth = 0; root.key = search_rule == 0 ? root.dual_bound : 0.0;
     root.b_idx = -1; root.b_dir = 0; root.b_val = 0.0; root.slot = 0;
+    t->nodes.reserve((size_t)std::min<int64_t>(2 * t->capacity, (int64_t)1 << 22));  // (grows beyond: every node ever created)
     t->nodes.push_back(root);
     *out = t;
     return MIPX_OK;
