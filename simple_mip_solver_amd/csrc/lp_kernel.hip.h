@@ -334,6 +334,7 @@ struct Smem {
     double vb[NP];
     double d[NP];       // staging of the borders at setup / output (they live in the control wave's
     double key[NP];     //   registers in between); key: x assembly
+    double cvec[NP];    // objective coefficients (the objective is re-summed from x at the end)
     double beta0[MP];
     double ba[4 * NW * R];
     double bb[4 * NW * R];
@@ -684,6 +685,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         const double g_d = anchored ? avec[jc] : gc[jc];
         const int g_nv = anchored ? aidx[jc] : jc;
         const double g_lo = lk[jc], g_up = uk[jc];
+        const double g_c = gc[jc];
         const int8_t g_st = vin ? vin[vc] : (int8_t)0;
         if (tid < MP) {
             s.beta0[tid] = tid < m ? (anchored ? g_b0 : -g_b0) : 0.0;
@@ -696,6 +698,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
             s.up[tid] = tid < n ? g_up : 0.0;
             s.va[tid] = 0.0;
             s.vb[tid] = 0.0;
+            s.cvec[tid] = tid < n ? g_c : 0.0;
         }
         if (tid < NP + MP) {
             const int8_t st = tid < nv ? g_st : (int8_t)0;
@@ -1244,7 +1247,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             const int j = lane + 64 * k;
-            p[k] = j < n ? gc[j] * s.key[j] : 0.0;
+            p[k] = j < n ? s.cvec[j] * s.key[j] : 0.0;
         }
 #pragma unroll
         for (int h = PER / 2; h >= 1; h >>= 1) {
