@@ -707,6 +707,29 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
             s.pos[tid] = -1;
         }
     }
+    // the dive's branching rule (control wave): its candidates (n_int <= n <= NP: PJ per lane) and
+    // their pseudo-cost entries are fetched now, so that the rule finds them in registers
+    int ci[PJ];
+    bool cv[PJ], che[PJ];
+    double ccl[PJ], ccr[PJ];
+#pragma unroll
+    for (int kk = 0; kk < PJ; kk++) { ci[kk] = 0; cv[kk] = false; che[kk] = true; ccl[kk] = 0.0; ccr[kk] = 0.0; }
+    if (DIVE && ctl && g.dive) {
+#pragma unroll
+        for (int kk = 0; kk < PJ; kk++) {
+            const int k = lane + 64 * kk;
+            cv[kk] = k < g.n_int;
+            ci[kk] = g.int_idx[cv[kk] ? k : 0];
+        }
+        if (g.rule != 0) {
+#pragma unroll
+            for (int kk = 0; kk < PJ; kk++) {
+                che[kk] = g.has_entry[ci[kk]] != 0;
+                ccl[kk] = g.cost_l[ci[kk]];
+                ccr[kk] = g.cost_r[ci[kk]];
+            }
+        }
+    }
     if (tid == 0) s.seq = 0;
     KPROF_SETUP_MARK(9);
     __syncthreads();
@@ -1274,25 +1297,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         if (status == 0 && objv < g.dive_cutoff) {
             double bk = -INF;
             int bp = kNoCand, nprobe = 0;
-            // n_int <= n <= NP: PJ candidates per lane; the index loads, then the table loads, are
-            // issued together (two memory latencies for the whole rule instead of two per 64 variables)
-            int ci[PJ];
-            bool cv[PJ];
-#pragma unroll
-            for (int kk = 0; kk < PJ; kk++) {
-                const int k = lane + 64 * kk;
-                cv[kk] = k < g.n_int;
-                ci[kk] = g.int_idx[cv[kk] ? k : 0];
-            }
-            double ccl[PJ], ccr[PJ];
-            bool che[PJ];
-#pragma unroll
-            for (int kk = 0; kk < PJ; kk++) {
-                const bool pc = g.rule != 0;
-                che[kk] = pc ? g.has_entry[ci[kk]] != 0 : true;
-                ccl[kk] = pc ? g.cost_l[ci[kk]] : 0.0;
-                ccr[kk] = pc ? g.cost_r[ci[kk]] : 0.0;
-            }
+            // (candidates and their table entries were loaded at the start of the kernel)
 #pragma unroll
             for (int kk = 0; kk < PJ; kk++) {
                 const int k = lane + 64 * kk;
