@@ -386,3 +386,21 @@ def test_driver_options_for_the_native_mode():
         assert (bb._native_stats['dives'] > 0) == kw.get('dive', True)
     with pytest.raises(AssertionError, match='dive needs frontier_batch > 1'):
         BranchAndBound(make(), gomory_cuts=False, frontier_batch=1, dive=True)
+
+
+@pytest.mark.parametrize('Node', [DepthFirstSearchNode, PseudoCostBranchDepthFirstSearchNode])
+def test_depth_first_batches_with_the_default_dive(Node):
+    """Depth-first node classes in the batched native mode (anchor and dive on by default)."""
+    for seed in (3, 4):
+        make = lambda: random_model(30, 12, seed)
+        ref = BranchAndBound(make(), Node, pseudo_costs={}, gomory_cuts=False, frontier_batch=1)
+        ref.solve()
+        assert ref.status == 'optimal'
+        for batch in (8, 128):
+            bb = BranchAndBound(make(), Node, pseudo_costs={}, gomory_cuts=False, frontier_batch=batch,
+                                pool_capacity=1 << 15)
+            bb.solve()
+            assert bb.status == 'optimal' and isclose(bb.objective_value, ref.objective_value, abs_tol=1e-6)
+            assert bb._native_stats['dives'] > 0
+            x = bb.solution
+            assert np.max(np.abs(x - np.round(x))) <= 1e-4
