@@ -404,3 +404,18 @@ def test_depth_first_batches_with_the_default_dive(Node):
             assert bb._native_stats['dives'] > 0
             x = bb.solution
             assert np.max(np.abs(x - np.round(x))) <= 1e-4
+
+
+@pytest.mark.parametrize('Node', NODES)
+def test_example_models_batched_mode_with_defaults(Node):
+    """The 64 example models in the batched native mode (anchor + dive on by default): the optimum of
+    the committed HiGHS table within 1e-6, an integral feasible solution."""
+    for f, rec in sorted(TABLE.items()):
+        path = os.path.join(HERE, 'golden', 'example_models', f)
+        bb = BranchAndBound(MILPInstance(file_name=path), Node, pseudo_costs={}, gomory_cuts=False,
+                            frontier_batch=16, pool_capacity=1 << 13)
+        bb.solve()
+        assert bb.status == 'optimal' and isclose(bb.objective_value, rec['milp_opt'], abs_tol=1e-6), f
+        x = bb.solution
+        idx = bb.model.integerIndices
+        assert np.max(np.abs(x[idx] - np.round(x[idx]))) <= 1e-4, f
