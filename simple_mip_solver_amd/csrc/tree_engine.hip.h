@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <limits>
+#include <memory>
 #include <queue>
 
 #include "tree_kernels.hip.h"
@@ -24,7 +25,25 @@ struct NodeRec {
     int32_t depth;
     int32_t b_idx;       // variable branched on to create this node (-1 root)
     int32_t b_dir;       // 0 left (x <= floor), 1 right (x >= ceil)
-    int32_t born = 0;    // step that created the node (MIPX_TREE_PROFILE: age histogram)
+    int32_t born;        // step that created the node (MIPX_TREE_PROFILE: age histogram)
+    // (no default initialisers: a fresh block of the node table must not be touched page by page)
+};
+
+// The node table: every node ever created, indexed by id.  Blocks of 2^18 records instead of one
+// vector: growing never copies (a 5 M-node table is 240 MB -- one reallocation stalled the step
+// loop for 59 ms).
+struct NodeTable {
+    static constexpr int kShift = 18;
+    static constexpr size_t kMask = ((size_t)1 << kShift) - 1;
+    std::vector<std::unique_ptr<NodeRec[]>> blocks;
+    size_t n = 0;
+    NodeRec &operator[](size_t i) { return blocks[i >> kShift][i & kMask]; }
+    const NodeRec &operator[](size_t i) const { return blocks[i >> kShift][i & kMask]; }
+    void push_back(const NodeRec &r) {
+        if ((n >> kShift) == blocks.size()) blocks.emplace_back(new NodeRec[(size_t)1 << kShift]);
+        (*this)[n++] = r;
+    }
+    size_t size() const { return n; }
 };
 
 // CPython's heapq on node ids (Lib/heapq.py heappush/heappop/_siftdown/_siftup), so that ties are
@@ -226,7 +245,7 @@ struct mipx_tree {
     int8_t *pp_v = nullptr;
     int32_t *pp_status = nullptr;
     // host state
-    std::vector<NodeRec> nodes;
+    NodeTable nodes;
     std::vector<int32_t> free_slots;
     PyHeap heap;        // exact mode (max_batch == 1) and depth-first search
     BucketQueue bq;     // batched best-first search
@@ -863,8 +882,7 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     NodeRec root;
     root.dual_bound = -std::numeric_limits<double>::infinity();
     root.depth = 0; root.key = search_rule == 0 ? root.dual_bound : 0.0;
-    root.b_idx = -1; root.b_dir = 0; root.b_val = 0.0; root.slot = 0;
-    t->nodes.reserve((size_t)std::min<int64_t>(2 * t->capacity, (int64_t)1 << 22));  // (grows beyond: every node ever created)
+    root.b_idx = -1; root.b_dir = 0; root.b_val = 0.0; root.slot = 0; root.born = 0;
     t->nodes.push_back(root);
     *out = t;
     return MIPX_OK;
