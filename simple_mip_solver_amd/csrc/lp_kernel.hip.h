@@ -87,6 +87,8 @@ struct LpArgs {
     double dive_cutoff = 0.0;       // dive only below this objective (the incumbent at launch)
     int32_t *dive_var = nullptr, *dive_dir = nullptr;
     double *dive_val = nullptr;
+    int dive_preset = 0;            // 1: the kernel presets status[node + dive_off] = dive_var[node] = -1
+    int32_t *zero16 = nullptr;      // optional: 4 words zeroed by workgroup 0 (K4's request counter)
 };
 
 constexpr double kVarEps = 1e-4;  // utils/tolerance.py:2 variable_epsilon
@@ -731,6 +733,11 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         }
     }
     if (tid == 0) s.seq = 0;
+    if (DIVE && g.dive_preset && tid == 0) {
+        g.status[(size_t)node + (size_t)g.dive_off] = -1;
+        g.dive_var[node] = -1;
+    }
+    if (g.zero16 != nullptr && node == 0 && tid < 4) g.zero16[tid] = 0;
     KPROF_SETUP_MARK(9);
     __syncthreads();
     KPROF_SETUP_MARK(10);

@@ -202,6 +202,7 @@ struct StepBuf {
     std::vector<int32_t> slots, br_pos, br_slot, br_var, br_child;  // staging kept alive
     std::vector<int32_t> br2_pos, br2_slot, br2_var, br2_child, dive_slots;  // children of the dive children
     bool dive = false;  // this step was launched with the in-place dive
+    bool scored_once = false;  // K4 ran on this step (the first run's request counter was zeroed by K1)
     int B = 0;
     bool in_flight = false;
 };
@@ -223,6 +224,7 @@ struct mipx_tree {
     int32_t *d_int_idx = nullptr, *d_pairs = nullptr, *d_pairs2 = nullptr;
     double *d_cost_l = nullptr, *d_cost_r = nullptr, *d_cost_l2 = nullptr, *d_cost_r2 = nullptr;
     uint8_t *d_has = nullptr, *d_has2 = nullptr;
+    char *h_tab = nullptr;  // pinned mirror of [cost_l | cost_r | has_entry]: d_cost_l .. d_has are one allocation
     hipStream_t st2 = nullptr;  // strong-branching probes + re-scoring run beside the step in flight
     hipStream_t st3 = nullptr;  // children records of step k are written beside the node LPs of step k+1
     hipEvent_t ev_child = nullptr;
@@ -336,6 +338,8 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
         a.int_idx = t->d_int_idx; a.cost_l = t->d_cost_l; a.cost_r = t->d_cost_r; a.has_entry = t->d_has;
         a.dive_cutoff = t->primal;
         a.dive_var = dive->d_dvar; a.dive_dir = dive->d_ddir; a.dive_val = dive->d_dval;
+        a.dive_preset = 1;           // the kernel itself marks "no child / no dive" first
+        a.zero16 = dive->d_ask_count; // and zeroes K4's request counter
     }
     a.m = t->m; a.n = t->n;
     a.A = t->prob->dA; a.b = t->prob->db; a.c = t->prob->dc;
@@ -377,7 +381,9 @@ int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false) {
     s.probe_list = S.d_plist;
     s.ask_count = S.d_ask_count; s.ask_cap = kAskCap; s.ask = side ? nullptr : S.d_ask;
     s.ask_nodes = S.B;  // dive children (positions >= B) are never probed in their own step
-    if (!side) HIP_TRY(t->ctx, hipMemsetAsync(S.d_ask_count, 0, 16, t->ctx->stream));
+    if (!side && !(S.dive && batch == 2 * S.B && !S.scored_once))
+        HIP_TRY(t->ctx, hipMemsetAsync(S.d_ask_count, 0, 16, t->ctx->stream));
+    S.scored_once = true;
     hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, side ? t->st2 : t->ctx->stream, s);
     HIP_TRY(t->ctx, hipGetLastError());
     return MIPX_OK;
@@ -447,9 +453,12 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
     t->phase_ms[0] += std::chrono::duration<double, std::milli>(now() - tp).count();
     if (t->table_dirty) {  // pseudo-cost table as of the last finished step
         const size_t n = t->n;
-        HIP_TRY(ctx, hipMemcpyAsync(t->d_cost_l, t->cost_l.data(), n * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(t->d_cost_r, t->cost_r.data(), n * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(t->d_has, t->has_entry.data(), n, hipMemcpyHostToDevice, st));
+        // (one copy from the pinned mirror; the previous upload has long been consumed: two steps ago)
+        char *ht = t->h_tab + (size_t)(t->steps & 1) * 17 * n;  // (two mirrors, alternating)
+        std::memcpy(ht, t->cost_l.data(), n * 8);
+        std::memcpy(ht + n * 8, t->cost_r.data(), n * 8);
+        std::memcpy(ht + 2 * n * 8, t->has_entry.data(), n);
+        HIP_TRY(ctx, hipMemcpyAsync(t->d_cost_l, ht, 17 * n, hipMemcpyHostToDevice, st));
         t->table_dirty = false;
     }
     std::memcpy(S.h_slot, slots.data(), (size_t)B * 4);
@@ -460,10 +469,7 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
         t->child_pending = false;
     }
     S.dive = t->dive && pick_cfg(t->m, t->n) != nullptr;
-    if (S.dive) {  // no child / no dive until the kernel says otherwise
-        HIP_TRY(ctx, hipMemsetAsync(S.d_status + B, 0xff, (size_t)B * 4, st));
-        HIP_TRY(ctx, hipMemsetAsync(S.d_dvar, 0xff, (size_t)B * 4, st));
-    }
+    S.scored_once = false;
     HIP_TRY(ctx, hipEventRecord(S.e0, st));
     int rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, S.d_slot, 0, S.d_status, S.d_obj,
                        S.d_x, S.d_vout, S.d_iters, S.d_npiv, nullptr, S.dive ? &S : nullptr);
@@ -856,8 +862,14 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
         if (hipEventCreate(&S.e0) != hipSuccess || hipEventCreate(&S.e1) != hipSuccess ||
             hipEventCreate(&S.done) != hipSuccess) rc |= MIPX_EHIP;
     }
-    rc |= dmalloc(ctx, &t->d_cost_l, n); rc |= dmalloc(ctx, &t->d_cost_r, n);
-    rc |= dmalloc(ctx, &t->d_has, n);
+    {   // [cost_l | cost_r | has_entry] in one allocation: one upload per step
+        char *tab = nullptr;
+        rc |= dmalloc(ctx, &tab, 17 * n);
+        t->d_cost_l = (double *)tab;
+        t->d_cost_r = tab ? (double *)(tab + 8 * n) : nullptr;
+        t->d_has = tab ? (uint8_t *)(tab + 16 * n) : nullptr;
+        if (hipHostMalloc((void **)&t->h_tab, 2 * 17 * n, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
+    }
     if (branch_rule == 1) {
         rc |= dmalloc(ctx, &t->pp_l, pc * n); rc |= dmalloc(ctx, &t->pp_u, pc * n);
         rc |= dmalloc(ctx, &t->pp_v, pc * nv); rc |= dmalloc(ctx, &t->pp_obj, pc);
@@ -901,8 +913,9 @@ void mipx_tree_destroy(mipx_tree *t) {
     if (t->ev_child) (void)hipEventDestroy(t->ev_child);
     if (t->h_pairs) (void)hipHostFree(t->h_pairs);
     if (t->h_pres) (void)hipHostFree(t->h_pres);
+    if (t->h_tab) (void)hipHostFree(t->h_tab);
     void *ptrs[] = {t->pool_a, t->atab_T, t->atab_vec, t->atab_idx, t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_pairs, t->d_pairs2, t->d_cost_l,
-                    t->d_cost_r, t->d_has, t->d_cost_l2, t->d_cost_r2, t->d_has2, t->pp_l, t->pp_u, t->pp_v, t->pp_obj, t->pp_status};
+                    t->d_cost_l2, t->d_cost_r2, t->d_has2, t->pp_l, t->pp_u, t->pp_v, t->pp_obj, t->pp_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (StepBuf &S : t->buf) {
