@@ -49,9 +49,10 @@ struct LpArgs {
     // instead of from the slack basis (fewer pivots when the bases are close, e.g. the root's)
     const double *anchor_T, *anchor_vec;
     const int32_t *anchor_idx;
-    // optional table of anchors (frontier engine): node k starts from entry anchor_sel[row of k in
-    // the node pool] of the table (same layout per entry, entries m*n / n+3m / 2n+m apart), or from
-    // the single anchor above where the entry is -1.  Register kernels only.
+    // optional table of anchors (frontier engine): node k of the batch starts from entry
+    // anchor_sel[k] of the table (same layout per entry, entries m*n / n+3m / 2n+m apart), or from
+    // the single anchor above where the entry is -1.  Indexed by batch position like `slot`, so that
+    // both loads leave together.  Register kernels only.
     const int32_t *anchor_sel = nullptr;
     const double *atab_T = nullptr, *atab_vec = nullptr;
     const int32_t *atab_idx = nullptr;
@@ -637,7 +638,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     const int8_t *vin = g.vstat_in ? g.vstat_in + src * nv : nullptr;
 
     // ---- 0. T = -A, beta0 = -b, d = c, slack basis (or the anchor's tableau state) -----------
-    const int asel = (g.anchor_sel != nullptr && vin != nullptr) ? __builtin_amdgcn_readfirstlane(g.anchor_sel[src]) : -1;
+    const int asel = (g.anchor_sel != nullptr && g.vstat_in != nullptr) ? __builtin_amdgcn_readfirstlane(g.anchor_sel[node]) : -1;
     const double *aT = asel >= 0 ? g.atab_T + (size_t)asel * ((size_t)m * n) : g.anchor_T;
     const double *avec = asel >= 0 ? g.atab_vec + (size_t)asel * (size_t)(n + 3 * m) : g.anchor_vec;
     const int32_t *aidx = asel >= 0 ? g.atab_idx + (size_t)asel * (size_t)(2 * n + m) : g.anchor_idx;

@@ -25,6 +25,7 @@ struct NodeRec {
     int32_t depth;
     int32_t b_idx;       // variable branched on to create this node (-1 root)
     int32_t b_dir;       // 0 left (x <= floor), 1 right (x >= ceil)
+    int32_t anchor;      // entry of the anchor table its warm start refactors from (-1: the root's)
     int32_t born;        // step that created the node (MIPX_TREE_PROFILE: age histogram)
     // (no default initialisers: a fresh block of the node table must not be touched page by page)
 };
@@ -217,7 +218,6 @@ struct mipx_tree {
     // device pool + per-step buffers
     double *pool_l = nullptr, *pool_u = nullptr;
     int8_t *pool_v = nullptr;
-    int32_t *pool_a = nullptr;     // anchor-table entry per pool row (-1: the problem's single anchor)
     double *atab_T = nullptr, *atab_vec = nullptr;   // mipx_tree_reanchor: one anchor per re-anchored node
     int32_t *atab_idx = nullptr;
     int64_t atab_count = 0;
@@ -331,7 +331,7 @@ void tree_push(mipx_tree *t, int64_t id) {
 int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const int8_t *v,
               const int32_t *slot, int max_iter, int32_t *status, double *obj, double *x,
               int8_t *vout, int32_t *iters, int32_t *npiv, hipStream_t stream = nullptr,
-              const StepBuf *dive = nullptr) {
+              const StepBuf *dive = nullptr, const int32_t *asel = nullptr) {
     mipx::LpArgs a;
     if (dive) {  // in-place dive: K4's rule inside K1, children at positions batch .. 2 * batch - 1
         a.dive = 1; a.dive_off = batch; a.rule = t->rule; a.n_int = t->n_int;
@@ -348,8 +348,8 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
     a.anchor_T = t->prob->anchor_on ? t->prob->anchor_T : nullptr;
     a.anchor_vec = t->prob->anchor_on ? t->prob->anchor_vec : nullptr;
     a.anchor_idx = t->prob->anchor_on ? t->prob->anchor_idx : nullptr;
-    if (slot != nullptr && t->atab_T != nullptr) {  // node LPs: the anchor their record names
-        a.anchor_sel = t->pool_a; a.atab_T = t->atab_T; a.atab_vec = t->atab_vec; a.atab_idx = t->atab_idx;
+    if (asel != nullptr && t->atab_T != nullptr) {  // node LPs: the anchor their record names
+        a.anchor_sel = asel; a.atab_T = t->atab_T; a.atab_vec = t->atab_vec; a.atab_idx = t->atab_idx;
     }
     a.refactor_only = 0;
     a.status = status; a.obj = obj; a.x = x; a.y = nullptr; a.vstat_out = vout;
@@ -462,7 +462,8 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
         t->table_dirty = false;
     }
     std::memcpy(S.h_slot, slots.data(), (size_t)B * 4);
-    HIP_TRY(ctx, hipMemcpyAsync(S.d_slot, S.h_slot, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    for (int k = 0; k < B; k++) S.h_slot[B + k] = S.recs[(size_t)k].anchor;  // [pool rows | anchor-table entries]
+    HIP_TRY(ctx, hipMemcpyAsync(S.d_slot, S.h_slot, (size_t)B * 8, hipMemcpyHostToDevice, st));
     // 2. LP relaxations + scoring (after the children records of the last finished step)
     if (t->child_pending) {
         HIP_TRY(ctx, hipStreamWaitEvent(st, t->ev_child, 0));
@@ -472,7 +473,7 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
     S.scored_once = false;
     HIP_TRY(ctx, hipEventRecord(S.e0, st));
     int rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, S.d_slot, 0, S.d_status, S.d_obj,
-                       S.d_x, S.d_vout, S.d_iters, S.d_npiv, nullptr, S.dive ? &S : nullptr);
+                       S.d_x, S.d_vout, S.d_iters, S.d_npiv, nullptr, S.dive ? &S : nullptr, S.d_slot + B);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(S.e1, st));
     if ((rc = launch_score(t, S, S.dive ? 2 * B : B))) return rc;
@@ -665,7 +666,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     // One evaluated node at output position pos.  level 0: a node of the batch (pool row
     // `slot`); level 1: a dive child.  Returns the id of the child that was solved in place by
     // the dive (to be evaluated next), or -1.
-    auto evaluate = [&](int64_t id, int pos, int32_t slot, int level, int depth, int &err) -> int64_t {
+    auto evaluate = [&](int64_t id, int pos, int32_t slot, int level, int depth, int32_t anchor, int &err) -> int64_t {
         t->evaluated++;
         const bool lp_feasible = status[pos] == 0 || status[pos] == 2;
         if (status[pos] == 2) t->unbounded = true;
@@ -692,6 +693,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
                     c.key = t->search == 0 ? c.dual_bound : -(double)c.depth;
                     c.b_idx = branched_on; c.b_dir = dir; c.b_val = xv;
                     c.born = (int32_t)t->steps;
+                    c.anchor = anchor;
                     c.slot = t->free_slots.back();
                     t->free_slots.pop_back();
                     (level == 0 ? br_child : br2_child).push_back(c.slot);
@@ -718,14 +720,14 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     };
     for (int k = 0; k < B; k++) {
         int err = MIPX_OK;
-        const int64_t cid = evaluate(ids[k], k, slots[k], 0, S.recs[k].depth, err);
+        const int64_t cid = evaluate(ids[k], k, slots[k], 0, S.recs[k].depth, S.recs[k].anchor, err);
         if (err) return err;
         if (cid >= 0) {
             const int32_t cslot = t->nodes[cid].slot;
             t->lps++;
             t->dives++;
             t->pivots += npiv[B + k];
-            evaluate(cid, B + k, cslot, 1, S.recs[k].depth + 1, err);
+            evaluate(cid, B + k, cslot, 1, S.recs[k].depth + 1, S.recs[k].anchor, err);
             if (err) return err;
             dive_slots.push_back(cslot);  // its record row feeds its own children below
             t->nodes[cid].slot = -1;
@@ -767,7 +769,6 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             ca.x = S.d_x; ca.vstat = S.d_vout;
             ca.dst_l = t->pool_l; ca.dst_u = t->pool_u; ca.dst_v = t->pool_v;
             ca.child_slot = dp + 3 * cnt;
-            ca.src_a = t->pool_a; ca.dst_a = t->pool_a;
             hipLaunchKernelGGL(mipx::make_children, dim3(2 * cnt), dim3(256), 0, cs, ca);
             HIP_TRY(ctx, hipGetLastError());
             return MIPX_OK;
@@ -822,8 +823,6 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     int rc = 0;
     rc |= dmalloc(ctx, &t->pool_l, cap * n); rc |= dmalloc(ctx, &t->pool_u, cap * n);
     rc |= dmalloc(ctx, &t->pool_v, cap * nv);
-    rc |= dmalloc(ctx, &t->pool_a, cap);
-    if (t->pool_a && hipMemset(t->pool_a, 0xff, cap * 4) != hipSuccess) rc |= MIPX_EHIP;
     rc |= dmalloc(ctx, &t->d_int_idx, (size_t)n_int);
     rc |= dmalloc(ctx, &t->d_pairs, 5 * (pc / 2 > 2 * B ? pc / 2 : 2 * B));   // (second half: children of dive children)
     rc |= dmalloc(ctx, &t->d_pairs2, 5 * (pc / 2 > 2 * B ? pc / 2 : 2 * B));
@@ -840,14 +839,14 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
         hipEventCreateWithFlags(&t->ev_child, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&t->h_pairs, 10 * B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
     for (StepBuf &S : t->buf) {
-        rc |= dmalloc(ctx, &S.d_slot, B);
+        rc |= dmalloc(ctx, &S.d_slot, 2 * B);   // [pool rows | anchor-table entries] of the batch
         // per-node outputs have 2 * B rows: the batch, then its dive children
         rc |= dmalloc(ctx, &S.d_iters, 2 * B);
         S.ask_off = (2 * B * (2 * 8 + 5 * 4) + B * (8 + 2 * 4) + 15) / 16 * 16;
         S.pack_bytes = S.ask_off + 16 + (size_t)kAskCap * sizeof(mipx::ScoreArgs::Ask);
         rc |= dmalloc(ctx, &S.d_pack, S.pack_bytes);
         if (hipHostMalloc((void **)&S.h_pack, S.pack_bytes, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void **)&S.h_slot, B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
+            hipHostMalloc((void **)&S.h_slot, 2 * B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
         if (S.d_pack) {
             S.d_obj = (double *)S.d_pack; S.d_bval = S.d_obj + 2 * B; S.d_dval = S.d_bval + 2 * B;
             S.d_status = (int32_t *)(S.d_dval + B); S.d_bidx = S.d_status + 2 * B; S.d_mipf = S.d_bidx + 2 * B;
@@ -894,7 +893,7 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     NodeRec root;
     root.dual_bound = -std::numeric_limits<double>::infinity();
     root.depth = 0; root.key = search_rule == 0 ? root.dual_bound : 0.0;
-    root.b_idx = -1; root.b_dir = 0; root.b_val = 0.0; root.slot = 0; root.born = 0;
+    root.b_idx = -1; root.b_dir = 0; root.b_val = 0.0; root.slot = 0; root.born = 0; root.anchor = -1;
     t->nodes.push_back(root);
     *out = t;
     return MIPX_OK;
@@ -914,7 +913,7 @@ void mipx_tree_destroy(mipx_tree *t) {
     if (t->h_pairs) (void)hipHostFree(t->h_pairs);
     if (t->h_pres) (void)hipHostFree(t->h_pres);
     if (t->h_tab) (void)hipHostFree(t->h_tab);
-    void *ptrs[] = {t->pool_a, t->atab_T, t->atab_vec, t->atab_idx, t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_pairs, t->d_pairs2, t->d_cost_l,
+    void *ptrs[] = {t->atab_T, t->atab_vec, t->atab_idx, t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_pairs, t->d_pairs2, t->d_cost_l,
                     t->d_cost_l2, t->d_cost_r2, t->d_has2, t->pp_l, t->pp_u, t->pp_v, t->pp_obj, t->pp_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -1082,11 +1081,14 @@ int mipx_tree_reanchor(mipx_tree *t, int64_t max_nodes) {
     HIP_TRY(ctx, hipMalloc((void **)&nT, (size_t)K * m * n * 8));
     HIP_TRY(ctx, hipMalloc((void **)&nvec, (size_t)K * (n + 3 * m) * 8));
     HIP_TRY(ctx, hipMalloc((void **)&nidx, (size_t)K * (2 * n + m) * 4));
-    HIP_TRY(ctx, hipMalloc((void **)&d_sl, (size_t)K * 4));
-    std::vector<int32_t> sl((size_t)K);
-    for (int64_t k = 0; k < K; k++) sl[(size_t)k] = t->nodes[order[(size_t)k]].slot;
+    HIP_TRY(ctx, hipMalloc((void **)&d_sl, (size_t)K * 8));
+    std::vector<int32_t> sl(2 * (size_t)K);  // [pool rows | the anchors the nodes have now]
+    for (int64_t k = 0; k < K; k++) {
+        sl[(size_t)k] = t->nodes[order[(size_t)k]].slot;
+        sl[(size_t)(K + k)] = t->nodes[order[(size_t)k]].anchor;
+    }
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(d_sl, sl.data(), (size_t)K * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_sl, sl.data(), (size_t)K * 8, hipMemcpyHostToDevice, st));
     // refactor-only solves of the K nodes (from the anchors they have now), every final tableau dumped
     mipx::LpArgs a;
     a.m = t->m; a.n = t->n;
@@ -1096,24 +1098,20 @@ int mipx_tree_reanchor(mipx_tree *t, int64_t max_nodes) {
     a.anchor_T = t->prob->anchor_on ? t->prob->anchor_T : nullptr;
     a.anchor_vec = t->prob->anchor_on ? t->prob->anchor_vec : nullptr;
     a.anchor_idx = t->prob->anchor_on ? t->prob->anchor_idx : nullptr;
-    if (t->atab_T != nullptr) { a.anchor_sel = t->pool_a; a.atab_T = t->atab_T; a.atab_vec = t->atab_vec; a.atab_idx = t->atab_idx; }
+    if (t->atab_T != nullptr) { a.anchor_sel = d_sl + K; a.atab_T = t->atab_T; a.atab_vec = t->atab_vec; a.atab_idx = t->atab_idx; }
     a.refactor_only = 1;
     a.status = nullptr; a.obj = nullptr; a.x = nullptr; a.y = nullptr; a.vstat_out = nullptr;
     a.iters = nullptr; a.npivots = nullptr; a.batch = (int)K;
     a.dbg_T = nT; a.dbg_vec = nvec; a.dbg_idx = nidx; a.dbg_all = 1;
     int rc = launch_lp_any(t->prob, a, (int)K, st);
     if (rc == MIPX_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, MIPX_EHIP, "mipx_tree_reanchor: launch failed");
-    if (rc == MIPX_OK) {
-        // the old table goes away: every row back to the single anchor, then the K new entries
-        const size_t cap = (size_t)t->capacity;
-        if (hipMemsetAsync(t->pool_a, 0xff, cap * 4, st) != hipSuccess) rc = MIPX_EHIP;
-        hipLaunchKernelGGL(mipx::set_anchor_ids, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, d_sl, (int)K, t->pool_a);
-        if (hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, MIPX_EHIP, "mipx_tree_reanchor: scatter failed");
-    }
     (void)hipFree(d_sl);
     if (rc != MIPX_OK) { (void)hipFree(nT); (void)hipFree(nvec); (void)hipFree(nidx); return rc; }
     if (t->atab_T) { (void)hipFree(t->atab_T); (void)hipFree(t->atab_vec); (void)hipFree(t->atab_idx); }
     t->atab_T = nT; t->atab_vec = nvec; t->atab_idx = nidx; t->atab_count = K;
+    // the old table is gone: every open node back to the root's anchor, then the K new entries
+    // (the host's node records are the authority; a step uploads its batch's entries with the rows)
+    for (size_t pos = 0; pos < order.size(); pos++) t->nodes[order[pos]].anchor = pos < (size_t)K ? (int32_t)pos : -1;
     return MIPX_OK;
 }
 
@@ -1212,15 +1210,11 @@ int64_t mipx_tree_peek_open(mipx_tree *t, int64_t max_nodes, double *l, double *
 /* Anchor-table entries of the open nodes, in the order of mipx_tree_peek_open (-1: the single anchor). */
 int64_t mipx_tree_peek_anchors(mipx_tree *t, int64_t max_nodes, int32_t *anchor) {
     if (!t || max_nodes < 0 || !anchor) return MIPX_EINVAL;
-    if (hipStreamSynchronize(t->ctx->stream) != hipSuccess || hipStreamSynchronize(t->st3) != hipSuccess) return MIPX_EHIP;
     std::vector<int64_t> order;
     tree_queue_ids(t, order);
-    const size_t cap = (size_t)t->capacity;
-    std::vector<int32_t> all(cap);
-    if (hipMemcpy(all.data(), t->pool_a, cap * 4, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
     int64_t k = 0;
     for (size_t pos = 0; pos < order.size() && k < max_nodes; pos++, k++)
-        anchor[k] = t->atab_T ? all[(size_t)t->nodes[order[pos]].slot] : -1;
+        anchor[k] = t->atab_T ? t->nodes[order[pos]].anchor : -1;
     return k;
 }
 

@@ -122,15 +122,7 @@ struct ChildArgs {
     double *dst_l, *dst_u;         // destination pool
     int8_t *dst_v;
     const int32_t *child_slot;     // 2*count: left (x <= floor) then right (x >= ceil)
-    const int32_t *src_a = nullptr;  // optional: anchor-table entry per pool row, inherited by the children
-    int32_t *dst_a = nullptr;
 };
-
-// anchor-table entries of freshly anchored nodes: pool_a[slot[k]] = k
-__global__ void set_anchor_ids(const int32_t *slot, int count, int32_t *pool_a) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < count) pool_a[slot[k]] = k;
-}
 
 __global__ __launch_bounds__(256) void make_children(ChildArgs g) {
     const int c = blockIdx.x;  // child number: pair = c / 2, direction = c % 2
@@ -151,7 +143,6 @@ __global__ __launch_bounds__(256) void make_children(ChildArgs g) {
         g.dst_u[ds * n + k] = up;
     }
     for (int k = threadIdx.x; k < nv; k += blockDim.x) g.dst_v[ds * nv + k] = g.vstat[pos * nv + k];
-    if (g.dst_a != nullptr && threadIdx.x == 0) g.dst_a[ds] = g.src_a != nullptr ? g.src_a[ps] : -1;
 }
 
 }  // namespace mipx
