@@ -243,17 +243,24 @@ def main():
     if rank == 0:
         A2, b2, c2, l2, u2, ints2 = random_dense_milp_arrays(80, 40, seed=0)
         p2 = _ffi.Problem(ctx, A2, b2, c2)
-        t2 = _ffi.Tree(p2, ints2, l2, u2, branch_rule='pseudo cost', max_batch=4096, pool_capacity=1 << 21)
-        if args.dive:
-            t2.set_dive(True)
-        tt = time.perf_counter()
-        s2 = t2.solve(mip_gap=1e-4, frontier_batch=4096, max_seconds=30.0)
+        best = None
+        for _ in range(3):  # a 25 ms solve: the fastest of three (allocation and first-touch effects)
+            t2 = _ffi.Tree(p2, ints2, l2, u2, branch_rule='pseudo cost', max_batch=4096, pool_capacity=1 << 21)
+            if args.dive:
+                t2.set_dive(True)
+            tt = time.perf_counter()
+            s2 = t2.solve(mip_gap=1e-4, frontier_batch=4096, max_seconds=30.0)
+            el2 = time.perf_counter() - tt
+            t2.close()
+            if best is None or el2 < best[0]:
+                best = (el2, s2)
+        el2, s2 = best
         tto = {'instance': '80 vars x 40 rows, seed 0, same generator, PseudoCostBranchNode best-first'
                            + (' + one-level dive' if args.dive else ''),
-               'seconds': time.perf_counter() - tt,
+               'seconds': el2,
                'status': _ffi.TREE_STATUS[s2['status']], 'objective': s2['primal_bound'],
                'nodes': s2['evaluated_nodes']}
-        t2.close(); p2.close()
+        p2.close()
 
     d = {k: after[k] - before[k] for k in ('lp_solved', 'probes_solved', 'pivots', 'evaluated_nodes',
                                            'kernel_ms', 'steps', 'dives')}
