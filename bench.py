@@ -94,6 +94,10 @@ def main():
             torch.cuda.synchronize()
 
     n, m, B = args.vars, args.cons, args.batch
+    tto_dive = args.dive
+    if _ffi.kernel_name(m, n) == 'lp_dual_simplex_big':
+        args.reanchor = 0  # (the HBM-streaming kernel keeps the single anchor and does not dive)
+        args.dive = 0
     ctx = _ffi.Context(gpu_index)
     A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=args.seed)
     prob = _ffi.Problem(ctx, A, b, c)
@@ -246,7 +250,7 @@ def main():
         best = None
         for _ in range(3):  # a 25 ms solve: the fastest of three (allocation and first-touch effects)
             t2 = _ffi.Tree(p2, ints2, l2, u2, branch_rule='pseudo cost', max_batch=4096, pool_capacity=1 << 21)
-            if args.dive:
+            if tto_dive:
                 t2.set_dive(True)
             tt = time.perf_counter()
             s2 = t2.solve(mip_gap=1e-4, frontier_batch=4096, max_seconds=30.0)
@@ -256,7 +260,7 @@ def main():
                 best = (el2, s2)
         el2, s2 = best
         tto = {'instance': '80 vars x 40 rows, seed 0, same generator, PseudoCostBranchNode best-first'
-                           + (' + one-level dive' if args.dive else ''),
+                           + (' + one-level dive' if tto_dive else ''),
                'seconds': el2,
                'status': _ffi.TREE_STATUS[s2['status']], 'objective': s2['primal_bound'],
                'nodes': s2['evaluated_nodes']}
@@ -292,7 +296,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic',
             'config': {
-                'workload': f'C3: {n} vars x {m} rows random dense MILP (BASELINE.md sec. 4, seed '
+                'workload': f'{ {(256, 128): "C3", (1024, 512): "C5"}.get((n, m), "custom") }: {n} vars x {m} rows random dense MILP (BASELINE.md sec. 4, seed '
                             f'{args.seed}), PseudoCostBranchNode, best-first, strong_branch_iters=5, '
                             f'gomory_cuts=False, native frontier engine, {B} open nodes per step per GPU'
                             + (', every open node re-anchored after sharding' if args.reanchor and not args.no_anchor else '')
