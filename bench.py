@@ -96,8 +96,7 @@ def main():
     n, m, B = args.vars, args.cons, args.batch
     tto_dive = args.dive
     if _ffi.kernel_name(m, n) == 'lp_dual_simplex_big':
-        args.reanchor = 0  # (the HBM-streaming kernel keeps the single anchor and does not dive)
-        args.dive = 0
+        args.reanchor = 0  # (the HBM-streaming kernel keeps the single anchor)
     ctx = _ffi.Context(gpu_index)
     A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=args.seed)
     prob = _ffi.Problem(ctx, A, b, c)

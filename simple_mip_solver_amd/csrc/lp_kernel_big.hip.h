@@ -96,6 +96,15 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
         int npiv = 0, iters = 0, status = -1, phase = vin ? 0 : 1, w = 0, degen = 0;
         const int cap = 100 * (m + n) + 1000;
         const bool ctl = tid < CT;
+        // in-place dive (LpArgs::dive, like K1): pass 0 the node, pass 1 one child on the same slab
+        if (g.dive && g.dive_preset && tid == 0) {
+            g.status[(size_t)node + (size_t)g.dive_off] = -1;
+            g.dive_var[node] = -1;
+        }
+        if (g.zero16 != nullptr && node == 0 && tid < 4) g.zero16[tid] = 0;
+        int pass = 0;
+        size_t onode = (size_t)node;
+        for (;;) {  // passes
 
         for (;;) {
             int r = 0, q = 0, sigma = 1, newside = 0;
@@ -366,15 +375,15 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
             if (v < n) s_x[v] = fma(s_bb[i], kMReport, s_ba[i]);
         }
         __syncthreads();
-        if (g.x) for (int j = tid; j < n; j += NT) g.x[(size_t)node * n + j] = s_x[j];
+        if (g.x) for (int j = tid; j < n; j += NT) g.x[onode * n + j] = s_x[j];
         if (g.y) {
-            for (int i = tid; i < m; i += NT) g.y[(size_t)node * m + i] = 0.0;
+            for (int i = tid; i < m; i += NT) g.y[onode * m + i] = 0.0;
             __syncthreads();
             for (int j = tid; j < n; j += NT)
-                if (s_nvar[j] >= n) g.y[(size_t)node * m + (s_nvar[j] - n)] = s_d[j];
+                if (s_nvar[j] >= n) g.y[onode * m + (s_nvar[j] - n)] = s_d[j];
         }
         if (g.vstat_out) {
-            int8_t *vo = g.vstat_out + (size_t)node * nv;
+            int8_t *vo = g.vstat_out + onode * nv;
             for (int i = tid; i < m; i += NT) vo[s_bvar[i]] = 1;
             for (int j = tid; j < n; j += NT) vo[s_nvar[j]] = s_side[j] ? 2 : 3;
         }
@@ -406,13 +415,70 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
 #pragma unroll
             for (int h = 32; h >= 1; h >>= 1) sum = sum + __shfl_down(sum, h, 64);
             if (tid == 0) {
-                if (g.obj) g.obj[node] = status == 1 ? INF : sum;
-                if (g.status) g.status[node] = status;
-                if (g.iters) g.iters[node] = iters;
-                if (g.npivots) g.npivots[node] = npiv;
+                if (g.obj) g.obj[onode] = status == 1 ? INF : sum;
+                if (g.status) g.status[onode] = status;
+                if (g.iters) g.iters[onode] = iters;
+                if (g.npivots) g.npivots[onode] = npiv;
+            }
+            // the dive: K4's branching rule on the solution in s_x (wave 0), as in K1
+            if (g.dive && pass == 0) {
+                int code = -1, ddir = 0;
+                double dbound = 0.0;
+                const double objv = __shfl(sum, 0, 64);
+                if (status == 0 && objv < g.dive_cutoff) {
+                    double bk = -INF;
+                    int bp = kNoCand, nprobe = 0;
+                    for (int base = 0; base < g.n_int; base += 64) {
+                        const int k = base + lane;
+                        bool need_probe = false;
+                        if (k < g.n_int) {
+                            const int i = g.int_idx[k];
+                            const double v = s_x[i];
+                            const double fl = floor(v), ce = ceil(v);
+                            const double dist = fmin(v - fl, ce - v);
+                            const bool frac = dist > kVarEps;
+                            if (g.rule == 0) {
+                                keep(bk, bp, dist, k, frac);
+                            } else if (frac) {
+                                if (g.has_entry[i]) keep(bk, bp, fmin(g.cost_r[i] * (ce - v), g.cost_l[i] * (v - fl)), k, true);
+                                else need_probe = true;
+                            }
+                        }
+                        nprobe += __popcll(__ballot(need_probe));
+                    }
+                    double km;
+                    const int win = wave_argmax(bk, bp, km);
+                    if (win != kNoCand && nprobe == 0) {
+                        const int dvar = g.int_idx[win];
+                        const double v = s_x[dvar];
+                        const double fl = floor(v), ce = ceil(v);
+                        if (g.rule == 0) ddir = (v - fl <= ce - v) ? 0 : 1;
+                        else ddir = (g.cost_l[dvar] * (v - fl) <= g.cost_r[dvar] * (ce - v)) ? 0 : 1;
+                        dbound = ddir == 0 ? fl : ce;
+                        bool mine = false;  // a bound change in place needs the variable basic
+                        for (int i = lane; i < m; i += 64) mine |= s_bvar[i] == dvar;
+                        if (__any(mine)) {
+                            code = dvar;
+                            if (lane == 0) {
+                                g.dive_var[node] = dvar;
+                                g.dive_dir[node] = ddir;
+                                g.dive_val[node] = v;
+                                if (ddir == 0) s_up[dvar] = dbound;
+                                else s_lo[dvar] = dbound;
+                            }
+                        }
+                    }
+                }
+                if (lane == 0) s_ci[0] = code;
             }
         }
         __syncthreads();
+        if (!g.dive || pass != 0) break;
+        if (__builtin_amdgcn_readfirstlane(s_ci[0]) < 0) break;
+        pass = 1;
+        onode = (size_t)node + (size_t)g.dive_off;
+        npiv = 0; iters = 0; degen = 0; status = -1; phase = 2;  // (straight back into the iterations)
+        }  // passes
     }
 }
 

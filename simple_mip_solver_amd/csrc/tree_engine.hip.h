@@ -469,7 +469,7 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
         HIP_TRY(ctx, hipStreamWaitEvent(st, t->ev_child, 0));
         t->child_pending = false;
     }
-    S.dive = t->dive && pick_cfg(t->m, t->n) != nullptr;
+    S.dive = t->dive;  // (register tiles and the HBM-streaming kernel alike)
     S.scored_once = false;
     HIP_TRY(ctx, hipEventRecord(S.e0, st));
     int rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, S.d_slot, 0, S.d_status, S.d_obj,

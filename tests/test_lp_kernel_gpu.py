@@ -313,7 +313,7 @@ def _assert_same_dive(g, o, what=''):
     assert np.all(np.isposinf(g['obj'][g['status'] == 1]))
 
 
-@pytest.mark.parametrize('n,m,seed', [(24, 10, 1), (64, 32, 0), (100, 40, 2), (256, 128, 0)])
+@pytest.mark.parametrize('n,m,seed', [(24, 10, 1), (64, 32, 0), (100, 40, 2), (256, 128, 0), (300, 150, 1)])
 @pytest.mark.parametrize('rule', [0, 1])
 def test_in_place_dive_matches_oracle(n, m, seed, rule, gpu_ctx, oracle):
     """The dive (child LP continued on the register tableau after a bound of the branching
