@@ -95,8 +95,8 @@ def main():
 
     n, m, B = args.vars, args.cons, args.batch
     tto_dive = args.dive
-    if _ffi.kernel_name(m, n) == 'lp_dual_simplex_big':
-        args.reanchor = 0  # (the HBM-streaming kernel keeps the single anchor)
+    if _ffi.kernel_name(m, n) == 'lp_dual_simplex_big' and '--reanchor' not in sys.argv:
+        args.reanchor = 0  # (HBM-streaming kernel: a per-node 4 MB anchor costs more than the pivots it saves at this depth)
     ctx = _ffi.Context(gpu_index)
     A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=args.seed)
     prob = _ffi.Problem(ctx, A, b, c)

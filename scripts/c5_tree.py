@@ -17,6 +17,8 @@ st = t.stats()
 t0 = time.perf_counter()
 while st['open_nodes'] < B or st['evaluated_nodes'] == 0:
     st = t.solve(mip_gap=0.0, frontier_batch=min(B, 256), max_steps=1)
+if len(sys.argv) > 3 and sys.argv[3] != '0':
+    t.reanchor(st['open_nodes'])
 print('ramp-up: %d nodes, %d LPs, %.2f s, kernel %s' % (st['evaluated_nodes'], st['lp_solved'], time.perf_counter() - t0, _ffi.kernel_name(m, n)))
 b0 = t.stats(); t0 = time.perf_counter()
 st = t.solve(mip_gap=0.0, frontier_batch=B, max_steps=5)

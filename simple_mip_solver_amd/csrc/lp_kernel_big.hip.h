@@ -55,20 +55,25 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
         const double *lk = g.l + src * n, *uk = g.u + src * n;
         const int8_t *vin = g.vstat_in ? g.vstat_in + src * nv : nullptr;
         // ---- 0. T = -A, beta0 = -b, d = c, slack basis (or the anchor's tableau state) -------
-        const bool anchored = g.anchor_T != nullptr && vin != nullptr;
+        // (the anchor may come from the engine's table: entry anchor_sel[node], as in K1)
+        const int asel = (g.anchor_sel != nullptr && vin != nullptr) ? __builtin_amdgcn_readfirstlane(g.anchor_sel[node]) : -1;
+        const double *aT = asel >= 0 ? g.atab_T + (size_t)asel * ((size_t)m * n) : g.anchor_T;
+        const double *avec = asel >= 0 ? g.atab_vec + (size_t)asel * (size_t)(n + 3 * m) : g.anchor_vec;
+        const int32_t *aidx = asel >= 0 ? g.atab_idx + (size_t)asel * (size_t)(2 * n + m) : g.anchor_idx;
+        const bool anchored = aT != nullptr && vin != nullptr;
         if (anchored) {
-            for (size_t e = tid; e < (size_t)m * n; e += NT) T[e] = g.anchor_T[e];
+            for (size_t e = tid; e < (size_t)m * n; e += NT) T[e] = aT[e];
         } else {
             for (size_t e = tid; e < (size_t)m * n; e += NT) T[e] = -gA[e];
         }
         for (int i = tid; i < m; i += NT) {
-            s_beta0[i] = anchored ? g.anchor_vec[n + i] : -gb[i];
-            s_bvar[i] = anchored ? g.anchor_idx[n + i] : n + i;
+            s_beta0[i] = anchored ? avec[n + i] : -gb[i];
+            s_bvar[i] = anchored ? aidx[n + i] : n + i;
             s_ba[i] = 0.0; s_bb[i] = 0.0; s_entered[i] = 0;
         }
         for (int j = tid; j < n; j += NT) {
-            s_d[j] = anchored ? g.anchor_vec[j] : gc[j];
-            s_nvar[j] = anchored ? g.anchor_idx[j] : j;
+            s_d[j] = anchored ? avec[j] : gc[j];
+            s_nvar[j] = anchored ? aidx[j] : j;
             s_lo[j] = lk[j]; s_up[j] = uk[j];
             s_side[j] = 0; s_va[j] = 0.0; s_vb[j] = 0.0;
         }

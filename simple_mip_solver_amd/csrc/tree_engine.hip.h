@@ -1065,8 +1065,8 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
 int mipx_tree_reanchor(mipx_tree *t, int64_t max_nodes) {
     if (!t || max_nodes < 1) return MIPX_EINVAL;
     mipx_ctx *ctx = t->ctx;
-    if (!t->anchor_mode || !t->anchor_set || pick_cfg(t->m, t->n) == nullptr)
-        return fail(ctx, MIPX_EINVAL, "mipx_tree_reanchor: needs the anchor mode, a solved root and a register-tile shape");
+    if (!t->anchor_mode || !t->anchor_set)
+        return fail(ctx, MIPX_EINVAL, "mipx_tree_reanchor: needs the anchor mode and a solved root");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(t->st3));
     HIP_TRY(ctx, hipStreamSynchronize(t->st2));

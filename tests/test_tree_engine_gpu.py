@@ -307,14 +307,14 @@ def test_full_node_pool_stops_the_search_cleanly():
     assert bb.status == 'stopped on iterations or time'
 
 
-def test_reanchored_step_matches_the_oracle(oracle):
+@pytest.mark.parametrize('n,m,MB,K,target', [(64, 32, 1024, 200, 300), (300, 150, 256, 40, 60)])
+def test_reanchored_step_matches_the_oracle(n, m, MB, K, target, oracle):
     """mipx_tree_reanchor: open nodes get the tableau of their warm-start basis as their own anchor.
     The table is what the oracle builds for the same bases (refactor-only from the root's tableau), a
     warm start from one's own anchor needs no refactorisation pivot, and one engine step over all
     open nodes does exactly the pivots the oracle does on them with the same table."""
     from simple_mip_solver_amd import _ffi
     ctx = _ffi.default_context()
-    n, m, MB, K = 64, 32, 1024, 200
     A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=0)
     prob = _ffi.Problem(ctx, A, b, c)
 
@@ -323,7 +323,7 @@ def test_reanchored_step_matches_the_oracle(oracle):
         t.set_anchor_mode(True)
         t.set_dive(True)
         st = t.stats()
-        while st['open_nodes'] < 300:
+        while st['open_nodes'] < target:
             st = t.solve(mip_gap=0.0, frontier_batch=32, max_steps=1)
         return t, st
     t, st0 = ramp()
@@ -366,9 +366,10 @@ def test_reanchored_step_matches_the_oracle(oracle):
     assert (t.peek_anchors(10 ** 6) >= 0).sum() >= K
     t2, _ = ramp()
     t2.solve(mip_gap=0.0, frontier_batch=MB, max_steps=1)
-    a, b2 = (x.solve(mip_gap=0.0, frontier_batch=256, max_steps=6) for x in (t, t2))
+    a, b2 = (x.solve(mip_gap=0.0, frontier_batch=256, max_steps=3) for x in (t, t2))
     assert a['evaluated_nodes'] == b2['evaluated_nodes'] and isclose(a['dual_bound'], b2['dual_bound'], abs_tol=1e-7)
-    assert a['pivots'] < b2['pivots']
+    if target >= 300:   # (deep enough: near the root the root's own tableau is the closer anchor)
+        assert a['pivots'] < b2['pivots']
 
 
 def test_driver_options_for_the_native_mode():
