@@ -25,6 +25,8 @@ __host__ __device__ inline size_t big_lds_bytes(int m, int n) {
     return dbl * 8 + i32 * 4 + i8 + 64;
 }
 
+typedef double d2v __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *scratch) {
     constexpr int NT = kBigNT, NW = NT / 64, CT = 256;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -317,6 +319,49 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
             __syncthreads();
             {   // ---- stream the tableau: T_ij <- fma(-alpha_i, rho_j, T_ij) ---------------------
                 const bool vals = phase == 2;
+                if ((n & 1) == 0) {
+                    // adjacent column pairs: one 16-byte load / store per lane (1 KiB per wave
+                    // instruction), two rows of a wave in flight at a time
+                    d2v rj[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int j = 2 * lane + 128 * k;
+                        rj[k].x = (2 * k < PER && j < n) ? s_row[j] * pinv : 0.0;
+                        rj[k].y = (2 * k < PER && j + 1 < n) ? s_row[j + 1] * pinv : 0.0;
+                    }
+                    const int qk = q >> 7, ql = (q & 127) >> 1, qe = q & 1;
+                    for (int i0 = wave; i0 < m; i0 += 2 * NW) {
+                        const int i1 = i0 + NW;
+                        d2v *T0 = reinterpret_cast<d2v *>(T + (size_t)i0 * n);
+                        d2v *T1 = reinterpret_cast<d2v *>(T + (size_t)(i1 < m ? i1 : i0) * n);
+                        const double a0 = s_alpha[i0], a1 = s_alpha[i1 < m ? i1 : i0];
+                        d2v v0[8], v1[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const int jp = lane + 64 * k;  // pair index
+                            const bool in = 2 * k < PER && 2 * jp < n;
+                            v0[k] = in ? __builtin_nontemporal_load(T0 + jp) : d2v{0.0, 0.0};
+                            v1[k] = (in && i1 < m) ? __builtin_nontemporal_load(T1 + jp) : d2v{0.0, 0.0};
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const int jp = lane + 64 * k;
+                            const bool in = 2 * k < PER && 2 * jp < n;
+                            const bool qh = k == qk && lane == ql;  // this pair holds column q
+                            d2v o0, o1;
+                            o0.x = i0 == r ? rj[k].x : fma(-a0, rj[k].x, v0[k].x);
+                            o0.y = i0 == r ? rj[k].y : fma(-a0, rj[k].y, v0[k].y);
+                            o1.x = i1 == r ? rj[k].x : fma(-a1, rj[k].x, v1[k].x);
+                            o1.y = i1 == r ? rj[k].y : fma(-a1, rj[k].y, v1[k].y);
+                            if (qh) {
+                                const double c0 = i0 == r ? pinv : -a0 * pinv, c1 = i1 == r ? pinv : -a1 * pinv;
+                                if (qe == 0) { o0.x = c0; o1.x = c1; } else { o0.y = c0; o1.y = c1; }
+                            }
+                            if (in) __builtin_nontemporal_store(o0, T0 + jp);
+                            if (in && i1 < m) __builtin_nontemporal_store(o1, T1 + jp);
+                        }
+                    }
+                } else {
                 double rj[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
@@ -339,6 +384,7 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                             if (k < PER && j < n) Ti[j] = j == q ? -a * pinv : fma(-a, rj[k], Ti[j]);
                         }
                     }
+                }
                 }
                 const double rhon = b0r * pinv;
                 const double ta = (bar - la) * pinv, tb = (bbr - lb) * pinv;
