@@ -18,9 +18,11 @@ class Counting(lpmod.HipBackend):
 
 lpmod.set_backend(Counting())
 n, m = int(sys.argv[1]) if len(sys.argv) > 1 else 256, int(sys.argv[2]) if len(sys.argv) > 2 else 128
-limit = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+limit = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=0)
 model = MILPInstance(A=A, b=b, c=c, l=l, u=u, sense=['Min', '>='], integerIndices=list(ints), numVars=n)
+# (context creation, library load and first launches stay out of the timing)
+BranchAndBound(model, PseudoCostBranchNode, pseudo_costs={}, strong_branch_iters=5, gomory_cuts=False, node_limit=5).solve()
 for cuts in (False, True):
     bb = BranchAndBound(model, PseudoCostBranchNode, pseudo_costs={}, strong_branch_iters=5,
                         gomory_cuts=cuts, node_limit=limit)

@@ -19,6 +19,10 @@ struct mipx_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
+    // staging of the host-buffer cut entry points, grown on demand (a hipMalloc / hipFree pair per
+    // call cost more than the kernels between them)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
 };
 
 struct mipx_problem {
@@ -189,6 +193,7 @@ void mipx_ctx_destroy(mipx_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -527,8 +532,14 @@ int mipx_gomory_batch(mipx_problem *p, int batch, const double *l, const double 
                  o_vec = carve(B * (n + 3 * m) * 8), o_idx = carve(B * (2 * n + m) * 4),
                  o_nc = carve(B * 4), o_ri = carve(B * m * 4), o_pi = carve(B * m * n * 8),
                  o_p0 = carve(B * m * 8), o_sp = carve(B * m * n * 8), o_s0 = carve(B * m * 8);
-    char *base = nullptr;
-    HIP_TRY(ctx, hipMalloc((void **)&base, off));
+    if (off > ctx->scratch_bytes) {
+        if (ctx->scratch) (void)hipFree(ctx->scratch);
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->scratch, off));
+        ctx->scratch_bytes = off;
+    }
+    char *base = (char *)ctx->scratch;
     hipStream_t st = ctx->stream;
     int rc = MIPX_OK;
     auto up = [&](size_t o, const void *src, size_t bytes) {
@@ -563,7 +574,8 @@ int mipx_gomory_batch(mipx_problem *p, int batch, const double *l, const double 
         g.pi = (double *)(base + o_pi); g.pi0 = (double *)(base + o_p0);
         g.safe_pi = (double *)(base + o_sp); g.safe_pi0 = (double *)(base + o_s0);
         const size_t lds = (n + (size_t)p->m + 64) * 8 + (2 * (size_t)p->m + n) * 4 + 64;
-        hipLaunchKernelGGL((mipx::gomory_cuts<256>), dim3(batch), dim3(256), lds, st, g);
+        g.chunks = batch >= 256 ? 1 : (batch >= 32 ? 4 : 16);  // (enough workgroups to use the GPU either way)
+        hipLaunchKernelGGL((mipx::gomory_cuts<256>), dim3(batch * g.chunks), dim3(256), lds, st, g);
         if (hipGetLastError() != hipSuccess) rc = fail(ctx, MIPX_EHIP, "mipx_gomory_batch: launch");
     }
     auto down = [&](void *dst, size_t o, size_t bytes) {
@@ -573,7 +585,6 @@ int mipx_gomory_batch(mipx_problem *p, int batch, const double *l, const double 
     down(ncuts, o_nc, B * 4); down(row_idx, o_ri, B * m * 4); down(pi, o_pi, B * m * n * 8);
     down(pi0, o_p0, B * m * 8); down(safe_pi, o_sp, B * m * n * 8); down(safe_pi0, o_s0, B * m * 8);
     if (hipStreamSynchronize(st) != hipSuccess && rc == MIPX_OK) rc = fail(ctx, MIPX_EHIP, "mipx_gomory_batch: sync");
-    (void)hipFree(base);
     return rc;
 }
 
@@ -595,8 +606,14 @@ int mipx_cut_select_batch(mipx_ctx *ctx, int n, int batch, int kmax, const int32
     const size_t o_np = carve(B * 4), o_pi = carve(B * K * nn * 8), o_p0 = carve(B * K * 8),
                  o_x = carve(B * nn * 8), o_na = carve(B * 4), o_ad = carve(B * K * 4),
                  o_te = carve(B * 4), o_de = carve(B * K * 8);
-    char *base = nullptr;
-    HIP_TRY(ctx, hipMalloc((void **)&base, off));
+    if (off > ctx->scratch_bytes) {
+        if (ctx->scratch) (void)hipFree(ctx->scratch);
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->scratch, off));
+        ctx->scratch_bytes = off;
+    }
+    char *base = (char *)ctx->scratch;
     hipStream_t st = ctx->stream;
     int rc = MIPX_OK;
     auto up = [&](size_t o, const void *src, size_t bytes) {
@@ -624,7 +641,6 @@ int mipx_cut_select_batch(mipx_ctx *ctx, int n, int batch, int kmax, const int32
     down(nadded, o_na, B * 4); down(added, o_ad, B * K * 4); down(terminator, o_te, B * 4);
     down(depth, o_de, B * K * 8);
     if (hipStreamSynchronize(st) != hipSuccess && rc == MIPX_OK) rc = fail(ctx, MIPX_EHIP, "mipx_cut_select_batch: sync");
-    (void)hipFree(base);
     return rc;
 }
 

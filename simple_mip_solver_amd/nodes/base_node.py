@@ -24,6 +24,10 @@ _COUNTER_KEYS = ('total_cut_generation_iterations', 'total_iterations_gmic_creat
                  'total_number_gmic_removed')
 
 
+def _is_int_type(t):
+    return t is int or issubclass(t, int)
+
+
 def _is_nonneg_int(v):
     return isinstance(v, int) and v >= 0
 
@@ -36,7 +40,10 @@ class BaseNode:
                  b_dir=None, b_val=None, depth=0, ancestors=None, *args, **kwargs):
         # argument checks; messages as at reference base_node.py:49-71
         assert isinstance(lp, DenseLP), 'lp must be CyClpSimplex instance'
-        assert all(isinstance(i, int) and 0 <= i < lp.nVariables for i in integer_indices), \
+        # (same test as `all(isinstance(i, int) and 0 <= i < nVariables ...)`, at C speed: it runs
+        # for every node and n is in the hundreds)
+        assert all(map(_is_int_type, map(type, integer_indices))) and \
+            (len(integer_indices) == 0 or 0 <= min(integer_indices) <= max(integer_indices) < lp.nVariables), \
             'indices must match variables'
         assert idx is None or isinstance(idx, int), 'node idx must be integer if provided'
         assert len(set(integer_indices)) == len(integer_indices), 'indices must be distinct'
@@ -302,6 +309,10 @@ class BaseNode:
         from math import cos, radians
         from simple_mip_solver_amd.lp import get_backend
         names = list(self.cut_pool)
+        if not names:  # (what K3 answers for an empty pool, without the GPU round trip)
+            self.cut_generation_terminator = 'no cuts'
+            self._update_gmic_counts(cut_idxs={}, operation='added')
+            return {}
         x = self.lp.getVarByName('x')
         engine = None
         if len(self.solution) <= 1024:
@@ -514,6 +525,19 @@ class BaseNode:
     def _is_fractional(self, value):
         assert isinstance(value, (int, float)), 'value should be a number'
         return min(value - floor(value), ceil(value) - value) > tol.variable_epsilon
+
+    def _fractional_indices(self):
+        """The integer indices whose value in `solution` is fractional, in integer_indices order:
+        `[i for i in integer_indices if self._is_fractional(solution[i])]`, vectorised unless a
+        subclass brings its own `_is_fractional`."""
+        if type(self)._is_fractional is not BaseNode._is_fractional or '_is_fractional' in self.__dict__:
+            return [i for i in self._integer_indices if self._is_fractional(self.solution[i])]
+        idx = np.asarray(self._integer_indices, dtype=np.intp)
+        if idx.size == 0:
+            return []
+        x = np.asarray(self.solution, dtype=np.float64)[idx]
+        frac = np.minimum(x - np.floor(x), np.ceil(x) - x) > tol.variable_epsilon
+        return [int(i) for i in idx[frac]]
 
     @staticmethod
     def _get_fraction(value):

@@ -36,8 +36,7 @@ class PseudoCostBranchNode(BaseNode):
     def _update_pseudo_costs(self):
         """Strong-branch every fractional integer index without an entry, then account for the
         branch that created this node unless it was just initialised (reference :46-66)."""
-        fresh = [i for i in self._integer_indices
-                 if self._is_fractional(self.solution[i]) and i not in self.pseudo_costs]
+        fresh = [i for i in self._fractional_indices() if i not in self.pseudo_costs]
         stock = type(self)._strong_branch is BaseNode._strong_branch and \
             '_strong_branch' not in self.__dict__
         if fresh and stock:
@@ -86,10 +85,8 @@ class PseudoCostBranchNode(BaseNode):
         """argmax over fractional integer i of min(cost_up * (ceil - x), cost_down * (x - floor));
         ties go to the earliest index in integer_indices order (reference :118-133)."""
         best, best_score = None, None
-        for i in self._integer_indices:
+        for i in self._fractional_indices():
             x = self.solution[i]
-            if not self._is_fractional(x):
-                continue
             score = min(pseudo_costs[i]['right']['cost'] * (ceil(x) - x),
                         pseudo_costs[i]['left']['cost'] * (x - floor(x)))
             if best is None or score > best_score:
