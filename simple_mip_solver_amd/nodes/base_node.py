@@ -42,7 +42,7 @@ class BaseNode:
         assert isinstance(lp, DenseLP), 'lp must be CyClpSimplex instance'
         # (same test as `all(isinstance(i, int) and 0 <= i < nVariables ...)`, at C speed: it runs
         # for every node and n is in the hundreds)
-        assert all(map(_is_int_type, map(type, integer_indices))) and \
+        assert all(map(_is_int_type, set(map(type, integer_indices)))) and \
             (len(integer_indices) == 0 or 0 <= min(integer_indices) <= max(integer_indices) < lp.nVariables), \
             'indices must match variables'
         assert idx is None or isinstance(idx, int), 'node idx must be integer if provided'
