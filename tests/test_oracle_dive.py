@@ -1,0 +1,90 @@
+"""CPU checks of the oracle's restatement of the engine options (no GPU): the in-place dive and the
+per-node anchor table must describe the same LPs as plain solves do."""
+import numpy as np
+import pytest
+
+from simple_mip_solver_amd.generators import random_dense_milp_arrays
+
+
+@pytest.mark.parametrize('n,m,seed', [(24, 10, 1), (40, 16, 3), (64, 32, 0)])
+@pytest.mark.parametrize('rule', [0, 1])
+def test_dive_child_is_the_lp_of_the_moved_bound(n, m, seed, rule, oracle):
+    A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=seed)
+    root = oracle.lp_solve(A, b, c, l, u)
+    assert root['status'] == 0
+    rng = np.random.default_rng(seed)
+    cl, cr = rng.uniform(0.5, 4.0, n), rng.uniform(0.5, 4.0, n)
+    r = oracle.lp_solve_dive_batch(A, b, c, l[None], u[None], None, rule, ints, cl, cr, np.ones(n, np.uint8), np.inf)
+    # the parent is the plain solve
+    assert r['status'][0] == 0 and r['obj'][0] == root['obj'] and np.array_equal(r['x'][0], root['x'])
+    v, d, val = int(r['dive_var'][0]), int(r['dive_dir'][0]), float(r['dive_val'][0])
+    assert v in ints and val == root['x'][v] and min(val - np.floor(val), np.ceil(val) - val) > 1e-4
+    # the rule: most fractional / best pseudo-cost score, ties to the earliest index
+    x = root['x']
+    frac = [i for i in ints if min(x[i] - np.floor(x[i]), np.ceil(x[i]) - x[i]) > 1e-4]
+    if rule == 0:
+        key = {i: min(x[i] - np.floor(x[i]), np.ceil(x[i]) - x[i]) for i in frac}
+        assert d == (0 if val - np.floor(val) <= np.ceil(val) - val else 1)
+    else:
+        key = {i: min(cr[i] * (np.ceil(x[i]) - x[i]), cl[i] * (x[i] - np.floor(x[i]))) for i in frac}
+        assert d == (0 if cl[v] * (val - np.floor(val)) <= cr[v] * (np.ceil(val) - val) else 1)
+    best = max(key.values())
+    assert v == next(i for i in frac if key[i] == best)
+    # the child is the LP with that bound moved, warm-started from the parent's basis
+    l2, u2 = l.copy(), u.copy()
+    if d == 0:
+        u2[v] = np.floor(val)
+    else:
+        l2[v] = np.ceil(val)
+    again = oracle.lp_solve(A, b, c, l2, u2, r['vstat'][0])
+    assert again['status'] == r['status'][1]
+    if again['status'] == 0:
+        assert abs(again['obj'] - r['obj'][1]) < 1e-7
+        assert np.all(A @ r['x'][1] >= b - 1e-6) and np.all(r['x'][1] >= l2 - 1e-7) and np.all(r['x'][1] <= u2 + 1e-7)
+    assert r['npivots'][1] == r['iters'][1]          # no refactorisation: it continues on the tableau
+    # a cutoff below the objective, or a missing pseudo-cost entry, switches the dive off
+    off = oracle.lp_solve_dive_batch(A, b, c, l[None], u[None], None, rule, ints, cl, cr, np.ones(n, np.uint8), -1e30)
+    assert off['dive_var'][0] == -1 and off['status'][1] == -1
+    if rule == 1:
+        off = oracle.lp_solve_dive_batch(A, b, c, l[None], u[None], None, 1, ints, cl, cr, np.zeros(n, np.uint8), np.inf)
+        assert off['dive_var'][0] == -1
+
+
+def test_anchor_table_entries_are_used_per_node(oracle):
+    """Warm starts from a per-node table of anchors: from one's own basis no pivot is needed; the
+    optimum is that of the plain warm start."""
+    n, m = 40, 16
+    A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=3)
+    root = oracle.lp_solve(A, b, c, l, u)
+    x = root['x']
+    cand = [i for i in ints if min(x[i] - np.floor(x[i]), np.ceil(x[i]) - x[i]) > 1e-4][:3]
+    L, U = [], []
+    for i in cand:
+        for right in (0, 1):
+            l2, u2 = l.copy(), u.copy()
+            if right:
+                l2[i] = np.ceil(x[i])
+            else:
+                u2[i] = np.floor(x[i])
+            L.append(l2); U.append(u2)
+    L, U = np.array(L), np.array(U)
+    V = np.repeat(root['vstat'][None], len(L), axis=0)
+    kids = oracle.lp_solve_batch(A, b, c, L, U, V)
+    ok = np.where(kids['status'] == 0)[0]
+    assert len(ok) >= 2
+    anchors = [oracle.make_anchor(A, b, c, kids['vstat'][k]) for k in ok]
+    table = (np.stack([a['T'] for a in anchors]), np.stack([a['vec'] for a in anchors]),
+             np.stack([a['idx'] for a in anchors]))
+    # grandchildren-like LPs: the same bounds again, warm from each child's own final basis
+    sel = np.arange(len(ok), dtype=np.int32)
+    r = oracle.lp_solve_dive_batch(A, b, c, L[ok], U[ok], kids['vstat'][ok], -1, ints, np.zeros(n), np.zeros(n),
+                                   np.zeros(n, np.uint8), np.inf, anchor_table=table, anchor_sel=sel)
+    B = len(ok)
+    assert np.all(r['status'][:B] == 0) and np.all(r['npivots'][:B] == 0)         # already optimal, own anchor
+    assert np.allclose(r['obj'][:B], kids['obj'][ok], rtol=0, atol=1e-9)
+    # entry -1 falls back to the slack basis (no global anchor set): same optimum, some pivots
+    r2 = oracle.lp_solve_dive_batch(A, b, c, L[ok], U[ok], kids['vstat'][ok], -1, ints, np.zeros(n), np.zeros(n),
+                                    np.zeros(n, np.uint8), np.inf, anchor_table=table,
+                                    anchor_sel=np.full(B, -1, np.int32))
+    assert np.all(r2['status'][:B] == 0) and np.all(r2['npivots'][:B] > 0)
+    assert np.allclose(r2['obj'][:B], kids['obj'][ok], rtol=0, atol=1e-9)
