@@ -67,6 +67,11 @@ def main():
     ap.add_argument('--no-anchor', action='store_true',
                     help='refactor every node from the slack basis instead of the root tableau')
     args = ap.parse_args()
+    # stdout carries the one JSON line and nothing else: libraries that chat on fd 1 (RCCL prints a
+    # version banner there) are sent to stderr for the rest of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -327,7 +332,7 @@ def main():
                                  'tableau is register-resident, so real HBM traffic is far below'},
             'cpu_baseline': cpu,
         }
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     tree.close()
     if dist is not None:
         dist.barrier()
