@@ -168,6 +168,32 @@ int mipx_cut_select_batch(mipx_ctx *ctx, int n, int batch, int kmax, const int32
                           double max_abs_coef, int32_t *nadded, int32_t *added, int32_t *terminator,
                           double *depth);
 
+/*
+ * The rounding stage of the cut path on its own: utils/floating_point.py numerically_safe_cut
+ * (:40-103) -- scale_cut (:11-37), then per coefficient get_fraction (:106-167) with the
+ * good / exact approximation rule (:77-92) -- for `batch` supplied cuts of n coefficients.  The
+ * same device functions mipx_gomory_batch rounds with.
+ *   estimate       1 'over' (pi.x >= pi0 cuts: coefficients over-, right-hand side under-estimated),
+ *                  2 'under'
+ *   make_integer   0 / 1 (multiply through by the lcm of the denominators, :94-101)
+ *   max_term       largest numerator / denominator of a coefficient (tolerance.max_term)
+ *   safe_pi(0)     batch x n, batch
+ *   num, den       batch x (n+1) (may be NULL): numerator / denominator chosen per coefficient, then
+ *                  of the right-hand side -- integers held in doubles (exact: they are <= max_term,
+ *                  or a rounded |x| > max_term)
+ *   scaled_pi(0)   batch x n, batch (may be NULL): scale_cut's output
+ *   nonzero        batch (may be NULL): 0 where pi == 0 (the cut is returned unchanged)
+ * HOST pointers.
+ */
+int mipx_safe_cut_batch(mipx_ctx *ctx, int n, int batch, const double *pi, const double *pi0,
+                        int estimate, int make_integer, double max_term, double *safe_pi,
+                        double *safe_pi0, double *num, double *den, double *scaled_pi,
+                        double *scaled_pi0, int32_t *nonzero);
+/* get_fraction (utils/floating_point.py:106-167) for `count` numbers: x, max_term, estimate
+ * (0 none, 1 over, 2 under) per item -> numerator, denominator (integers held in doubles). */
+int mipx_get_fraction_batch(mipx_ctx *ctx, int count, const double *x, const double *max_term,
+                            const int32_t *estimate, double *num, double *den);
+
 /* Device memory owned by the library, for the device-resident entry points. */
 int mipx_dev_alloc(mipx_ctx *ctx, size_t bytes, void **dptr);
 int mipx_dev_free(mipx_ctx *ctx, void *dptr);

@@ -690,6 +690,63 @@ int mipx_oracle_safe_cut(int n, const double *pi, double pi0, int estimate, doub
     return 1;
 }
 
+/* The same with the chosen numerators / denominators reported (num, den: n + 1 entries, the
+ * right-hand side last; may be NULL) and the make_integer form of floating_point.py:94-101
+ * (np.lcm.reduce over the denominators as int64; coefficients (lcm * n) / d; the right-hand side
+ * is scaled by the lcm before it is rounded).  Mirrors mipx_safe_cut_batch of the product. */
+static void safe_coef(double coef, double max_term, int estimate, double *nn, double *dd) {
+    mipx_oracle_get_fraction(coef, max_term, estimate, nn, dd);
+    if (coef != 0.0 && fabs(1.0 - ((*nn / *dd) / coef)) > 1e-2) {
+        double n2, d2;
+        mipx_oracle_get_fraction(coef, max_term, EST_NONE, &n2, &d2);
+        if (fabs(n2 / d2 - coef) < 1e-14) { *nn = n2; *dd = d2; }
+    }
+}
+int mipx_oracle_safe_cut_ex(int n, const double *pi, double pi0, int estimate, double max_term,
+                            int make_integer, double *safe_pi, double *safe_pi0, double *num,
+                            double *den) {
+    double scale = INFINITY;
+    int any = 0;
+    for (int j = 0; j < n; j++) {
+        if (pi[j] != 0.0) any = 1;
+        const double s = fabs(1.0 / pi[j]);
+        if (s < scale) scale = s;
+    }
+    if (!any) {
+        for (int j = 0; j < n; j++) { safe_pi[j] = pi[j]; if (num) { num[j] = pi[j]; den[j] = 1.0; } }
+        *safe_pi0 = pi0;
+        if (num) { num[n] = pi0; den[n] = 1.0; }
+        return 0;
+    }
+    long long lcm = 1;
+    for (int j = 0; j < n; j++) {
+        double nn, dd;
+        safe_coef(pi[j] * scale, max_term, estimate, &nn, &dd);
+        if (num) { num[j] = nn; den[j] = dd; }
+        safe_pi[j] = nn / dd;
+        if (make_integer) {
+            const long long a = lcm < 0 ? -lcm : lcm, b = (long long)fabs(dd);
+            long long x = a, y = b;
+            while (y != 0) { const long long t = x % y; x = y; y = t; }
+            lcm = x == 0 ? 0 : (a / x) * b;
+        }
+    }
+    if (make_integer) {
+        for (int j = 0; j < n; j++) {
+            double nn, dd;
+            safe_coef(pi[j] * scale, max_term, estimate, &nn, &dd);
+            safe_pi[j] = (double)(lcm * (long long)nn) / dd;
+        }
+    }
+    double n0, d0;
+    const double s0 = pi0 * scale;
+    mipx_oracle_get_fraction(make_integer ? s0 * (double)lcm : s0, 1e3,
+                             estimate == EST_OVER ? EST_UNDER : EST_OVER, &n0, &d0);
+    *safe_pi0 = n0 / d0;
+    if (num) { num[n] = n0; den[n] = d0; }
+    return 1;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Gomory mixed-integer cuts from the condensed tableau (base_node.py:468-511): for every row whose
  * basic variable is an integer structural with fractional value (f0 in [0.01, 0.99]), in the

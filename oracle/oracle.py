@@ -186,6 +186,18 @@ def safe_cut(pi, pi0, estimate='over', max_term=1e3):
     return out, out0.value
 
 
+def safe_cut_ex(pi, pi0, estimate='over', make_integer=False, max_term=1e3):
+    """safe_cut with the chosen (numerator, denominator) per coefficient and for the right-hand
+    side (last entry), and the make_integer form: dict(safe_pi, safe_pi0, num, den)."""
+    pi = np.ascontiguousarray(pi, np.float64)
+    n = len(pi)
+    out = np.zeros(n); out0 = C.c_double(); num = np.zeros(n + 1); den = np.zeros(n + 1)
+    lib().mipx_oracle_safe_cut_ex(C.c_int(n), _p(pi, _dp), C.c_double(pi0), C.c_int(_EST[estimate]),
+                                  C.c_double(max_term), C.c_int(int(bool(make_integer))), _p(out, _dp),
+                                  C.byref(out0), _p(num, _dp), _p(den, _dp))
+    return dict(safe_pi=out, safe_pi0=out0.value, num=num.astype(np.int64), den=den.astype(np.int64))
+
+
 def gomory(A, b, c, l, u, vstat, x, int_idx, max_term=1e3):
     """GMI cuts (+ safe rounding) for the basis `vstat` of one node LP; x is the node's solution.
 

@@ -19,7 +19,8 @@ SYMBOLS = [
     'mipx_abi_version', 'mipx_device_count', 'mipx_ctx_create', 'mipx_ctx_destroy',
     'mipx_last_error', 'mipx_ctx_sync', 'mipx_problem_create', 'mipx_problem_destroy', 'mipx_problem_set_anchor',
     'mipx_tree_set_anchor_mode',
-    'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_lp_solve_multi', 'mipx_gomory_batch', 'mipx_cut_select_batch', 'mipx_dev_alloc', 'mipx_dev_free',
+    'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_lp_solve_multi', 'mipx_gomory_batch', 'mipx_cut_select_batch',
+    'mipx_safe_cut_batch', 'mipx_get_fraction_batch', 'mipx_dev_alloc', 'mipx_dev_free',
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
     'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
@@ -203,6 +204,44 @@ def select_cuts(ctx, pi, pi0, x, max_nonzero_coefs, min_cut_depth, cos_parallel,
                                      _ptr(added), _ptr(term), _ptr(depth))
     ctx.check(rc, 'mipx_cut_select_batch')
     return added[:nadded[0]].copy(), int(term[0]), depth[:K].copy()
+
+
+_EST = {None: 0, 'over': 1, 'under': 2}
+
+
+def safe_cut_batch(ctx, pi, pi0, estimate='over', make_integer=False, max_term=1e3):
+    """numerically_safe_cut for a batch of cuts on the device (mipx_safe_cut_batch): dict with
+    safe_pi, safe_pi0, num, den (batch x (n+1): the coefficients, then the right-hand side),
+    scaled_pi, scaled_pi0, nonzero."""
+    pi = np.ascontiguousarray(pi, dtype=np.float64)
+    if pi.ndim == 1:
+        pi = pi[None]
+    B, n = pi.shape
+    pi0 = np.ascontiguousarray(pi0, dtype=np.float64).reshape(B)
+    spi = np.zeros((B, n)); spi0 = np.zeros(B)
+    num = np.zeros((B, n + 1)); den = np.zeros((B, n + 1))
+    cpi = np.zeros((B, n)); cpi0 = np.zeros(B); nz = np.zeros(B, np.int32)
+    L = lib()
+    L.mipx_safe_cut_batch.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_double] + [_vp] * 7
+    rc = L.mipx_safe_cut_batch(ctx._h, n, B, _ptr(pi), _ptr(pi0), _EST[estimate], int(bool(make_integer)),
+                               float(max_term), _ptr(spi), _ptr(spi0), _ptr(num), _ptr(den), _ptr(cpi),
+                               _ptr(cpi0), _ptr(nz))
+    ctx.check(rc, 'mipx_safe_cut_batch')
+    return dict(safe_pi=spi, safe_pi0=spi0, num=num, den=den, scaled_pi=cpi, scaled_pi0=cpi0, nonzero=nz)
+
+
+def get_fraction_batch(ctx, x, max_term, estimate):
+    """get_fraction on the device for arrays x, max_term and a list of estimates (None/'over'/'under'):
+    (numerators, denominators) as int64 arrays."""
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+    mt = np.ascontiguousarray(np.broadcast_to(np.asarray(max_term, dtype=np.float64), x.shape))
+    est = np.ascontiguousarray([_EST[e] for e in estimate], dtype=np.int32)
+    num = np.zeros(len(x)); den = np.zeros(len(x))
+    L = lib()
+    L.mipx_get_fraction_batch.argtypes = [_vp, C.c_int] + [_vp] * 5
+    rc = L.mipx_get_fraction_batch(ctx._h, len(x), _ptr(x), _ptr(mt), _ptr(est), _ptr(num), _ptr(den))
+    ctx.check(rc, 'mipx_get_fraction_batch')
+    return num.astype(np.int64), den.astype(np.int64)
 
 
 def solve_multi(ctx, A, b, c, l, u, max_iter=0):

@@ -256,6 +256,17 @@ class BranchAndBound(BaseAlgorithm):
                 max_batch=self.frontier_batch, pool_capacity=self._pool_capacity)
             if self.primal_bound < INF:
                 self._native.set_primal_bound(self.primal_bound)
+            table = self._kwargs.get('pseudo_costs')
+            if pseudo and table:
+                # a table handed in by the caller (pseudo_cost.py:22: `pseudo_costs` is an input of
+                # bound) seeds the engine's; an entry counts as present once either side was visited
+                n = problem.n
+                cl, cr = np.zeros(n), np.zeros(n)
+                tl, tr = np.zeros(n, np.int32), np.zeros(n, np.int32)
+                for i, rec in table.items():
+                    cl[i], tl[i] = rec['left']['cost'], rec['left']['times']
+                    cr[i], tr[i] = rec['right']['cost'], rec['right']['times']
+                self._native.set_pseudo_cost_arrays(cl, cr, tl, tr)
             if self._anchor:
                 self._native.set_anchor_mode(True)
             if self._dive:

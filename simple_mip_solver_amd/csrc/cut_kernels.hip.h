@@ -69,6 +69,138 @@ __device__ inline void get_fraction_dev(double x, double max_term, int estimate,
     d_out = pick == 0 ? d1 : d2;
 }
 
+// one coefficient of numerically_safe_cut (utils/floating_point.py:77-92): the directed estimate,
+// replaced by the undirected one where that is exact to 1e-14 and the directed one is > 1 % off
+__device__ inline void safe_coef_dev(double coef, double max_term, int estimate, double &nn, double &dd) {
+    get_fraction_dev(coef, max_term, estimate, nn, dd);
+    if (coef != 0.0 && fabs(1.0 - ((nn / dd) / coef)) > kGoodEps) {
+        double n2, d2;
+        get_fraction_dev(coef, max_term, kEstNone, n2, d2);
+        if (fabs(n2 / d2 - coef) < kExactEps) { nn = n2; dd = d2; }
+    }
+}
+
+// ---- the rounding stage on its own (mipx_safe_cut_batch / mipx_get_fraction_batch): the same device
+// functions K2 rounds with, on supplied cuts, so that they can be pinned against the reference's
+// vectors (tests/golden/floating_point.json) in isolation ------------------------------------------
+struct SafeCutArgs {
+    int n, batch;
+    const double *pi, *pi0;        // batch x n, batch
+    int estimate;                  // kEstOver / kEstUnder (the right-hand side gets the other one)
+    int make_integer;              // multiply through by the lcm of the denominators
+    double max_term;
+    double *safe_pi, *safe_pi0;    // batch x n, batch
+    double *num, *den;             // batch x (n + 1): per coefficient, then the right-hand side (may be null)
+    double *scaled_pi, *scaled_pi0;  // scale_cut's output (may be null)
+    int32_t *nonzero;              // batch: 0 where pi == 0 (the cut is returned unchanged)
+};
+
+__global__ __launch_bounds__(256) void safe_cut_batch(SafeCutArgs g) {
+    __shared__ double red[8];
+    __shared__ double dens[256];
+    __shared__ long long lcm_s;
+    const int k = blockIdx.x;
+    if (k >= g.batch) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = g.n;
+    const double INF = __builtin_huge_val();
+    const double *pi = g.pi + (size_t)k * n;
+    double *out = g.safe_pi + (size_t)k * n;
+    // scale = min_j |1 / pi_j| (scale_cut, utils/floating_point.py:33-35; zeros give inf)
+    double smin = INF;
+    bool any = false;
+    for (int j = tid; j < n; j += 256) {
+        const double c = pi[j];
+        any |= c != 0.0;
+        smin = fmin(smin, fabs(1.0 / c));
+    }
+    smin = -wave_max_f64(-smin);
+    const int anyw = __any(any);
+    if (lane == 0) { red[wave] = smin; red[4 + wave] = anyw; }
+    __syncthreads();
+    double scale = INF;
+    bool nonzero = false;
+    for (int w = 0; w < 4; w++) { scale = fmin(scale, red[w]); nonzero |= red[4 + w] != 0.0; }
+    if (tid == 0 && g.nonzero) g.nonzero[k] = nonzero ? 1 : 0;
+    if (!nonzero) {
+        for (int j = tid; j < n; j += 256) {
+            out[j] = pi[j];
+            if (g.num) { g.num[(size_t)k * (n + 1) + j] = pi[j]; g.den[(size_t)k * (n + 1) + j] = 1.0; }
+            if (g.scaled_pi) g.scaled_pi[(size_t)k * n + j] = pi[j];
+        }
+        if (tid == 0) {
+            g.safe_pi0[k] = g.pi0[k];
+            if (g.num) { g.num[(size_t)k * (n + 1) + n] = g.pi0[k]; g.den[(size_t)k * (n + 1) + n] = 1.0; }
+            if (g.scaled_pi0) g.scaled_pi0[k] = g.pi0[k];
+        }
+        return;
+    }
+    // every coefficient; with make_integer the quotients wait for the lcm of the denominators
+    if (tid == 0) lcm_s = 1;
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+        const int j = base + tid;
+        double nn = 0.0, dd = 1.0;
+        if (j < n) {
+            const double coef = pi[j] * scale;
+            safe_coef_dev(coef, g.max_term, g.estimate, nn, dd);
+            if (g.scaled_pi) g.scaled_pi[(size_t)k * n + j] = coef;
+            if (g.num) { g.num[(size_t)k * (n + 1) + j] = nn; g.den[(size_t)k * (n + 1) + j] = dd; }
+            if (!g.make_integer) out[j] = nn / dd;
+        }
+        if (g.make_integer) {  // np.lcm.reduce over the denominators, in order (int64), by one thread
+            dens[tid] = j < n ? dd : 1.0;
+            __syncthreads();
+            if (tid == 0) {
+                long long l = lcm_s;
+                for (int q = 0; q < 256 && base + q < n; q++) {
+                    const long long a = l < 0 ? -l : l, b = (long long)fabs(dens[q]);
+                    long long x = a, y = b;
+                    while (y != 0) { const long long t = x % y; x = y; y = t; }
+                    l = x == 0 ? 0 : (a / x) * b;
+                }
+                lcm_s = l;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const long long lcm = lcm_s;
+    if (g.make_integer) {
+        for (int j = tid; j < n; j += 256) {
+            double nn, dd;
+            safe_coef_dev(pi[j] * scale, g.max_term, g.estimate, nn, dd);
+            // (lcm * n) / d as numpy does it: an int64 product, then a true division
+            out[j] = (double)(lcm * (long long)nn) / dd;
+        }
+    }
+    if (tid == 0) {
+        const double s0 = g.pi0[k] * scale;
+        if (g.scaled_pi0) g.scaled_pi0[k] = s0;
+        double n0, d0;
+        // (the reference passes no max_term for the right-hand side: its default, tolerance.max_term)
+        get_fraction_dev(g.make_integer ? s0 * (double)lcm : s0, 1e3,
+                         g.estimate == kEstOver ? kEstUnder : kEstOver, n0, d0);
+        g.safe_pi0[k] = n0 / d0;
+        if (g.num) { g.num[(size_t)k * (n + 1) + n] = n0; g.den[(size_t)k * (n + 1) + n] = d0; }
+    }
+}
+
+struct FractionArgs {
+    int count;
+    const double *x, *max_term;
+    const int32_t *estimate;
+    double *num, *den;
+};
+
+__global__ __launch_bounds__(256) void get_fraction_batch(FractionArgs g) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.count) return;
+    double nn, dd;
+    get_fraction_dev(g.x[i], g.max_term[i], g.estimate[i], nn, dd);
+    g.num[i] = nn;
+    g.den[i] = dd;
+}
+
 struct GomoryArgs {
     int m, n, batch;
     const double *A, *b;          // shared rows (m x n), rhs
@@ -224,12 +356,7 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
             for (int var = tid; var < n; var += NT) {
                 const double coef = pi_var[var] * scale;
                 double nn, dd;
-                get_fraction_dev(coef, g.max_term, kEstOver, nn, dd);
-                if (coef != 0.0 && fabs(1.0 - ((nn / dd) / coef)) > kGoodEps) {
-                    double n2, d2;
-                    get_fraction_dev(coef, g.max_term, kEstNone, n2, d2);
-                    if (fabs(n2 / d2 - coef) < kExactEps) { nn = n2; dd = d2; }
-                }
+                safe_coef_dev(coef, g.max_term, kEstOver, nn, dd);
                 out_sp[var] = nn / dd;
             }
             if (tid == 0) {

@@ -644,6 +644,93 @@ int mipx_cut_select_batch(mipx_ctx *ctx, int n, int batch, int kmax, const int32
     return rc;
 }
 
+int mipx_safe_cut_batch(mipx_ctx *ctx, int n, int batch, const double *pi, const double *pi0,
+                        int estimate, int make_integer, double max_term, double *safe_pi,
+                        double *safe_pi0, double *num, double *den, double *scaled_pi,
+                        double *scaled_pi0, int32_t *nonzero) {
+    if (!ctx || n <= 0 || batch < 0 || (estimate != 1 && estimate != 2) || !(max_term > 0) ||
+        (batch && (!pi || !pi0 || !safe_pi || !safe_pi0)) || ((num == nullptr) != (den == nullptr)))
+        return fail(ctx, MIPX_EINVAL, "mipx_safe_cut_batch: bad argument");
+    if (batch == 0) return MIPX_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t B = (size_t)batch, nn = (size_t)n;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_pi = carve(B * nn * 8), o_p0 = carve(B * 8), o_sp = carve(B * nn * 8), o_s0 = carve(B * 8),
+                 o_nu = carve(B * (nn + 1) * 8), o_de = carve(B * (nn + 1) * 8), o_cp = carve(B * nn * 8),
+                 o_c0 = carve(B * 8), o_nz = carve(B * 4);
+    if (off > ctx->scratch_bytes) {
+        if (ctx->scratch) (void)hipFree(ctx->scratch);
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->scratch, off));
+        ctx->scratch_bytes = off;
+    }
+    char *base = (char *)ctx->scratch;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_pi, pi, B * nn * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_p0, pi0, B * 8, hipMemcpyHostToDevice, st));
+    mipx::SafeCutArgs g;
+    g.n = n; g.batch = batch;
+    g.pi = (const double *)(base + o_pi); g.pi0 = (const double *)(base + o_p0);
+    g.estimate = estimate; g.make_integer = make_integer ? 1 : 0; g.max_term = max_term;
+    g.safe_pi = (double *)(base + o_sp); g.safe_pi0 = (double *)(base + o_s0);
+    g.num = (double *)(base + o_nu); g.den = (double *)(base + o_de);
+    g.scaled_pi = (double *)(base + o_cp); g.scaled_pi0 = (double *)(base + o_c0);
+    g.nonzero = (int32_t *)(base + o_nz);
+    hipLaunchKernelGGL(mipx::safe_cut_batch, dim3(batch), dim3(256), 0, st, g);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(safe_pi, base + o_sp, B * nn * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(safe_pi0, base + o_s0, B * 8, hipMemcpyDeviceToHost, st));
+    if (num) {
+        HIP_TRY(ctx, hipMemcpyAsync(num, base + o_nu, B * (nn + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(den, base + o_de, B * (nn + 1) * 8, hipMemcpyDeviceToHost, st));
+    }
+    if (scaled_pi) HIP_TRY(ctx, hipMemcpyAsync(scaled_pi, base + o_cp, B * nn * 8, hipMemcpyDeviceToHost, st));
+    if (scaled_pi0) HIP_TRY(ctx, hipMemcpyAsync(scaled_pi0, base + o_c0, B * 8, hipMemcpyDeviceToHost, st));
+    if (nonzero) HIP_TRY(ctx, hipMemcpyAsync(nonzero, base + o_nz, B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return MIPX_OK;
+}
+
+int mipx_get_fraction_batch(mipx_ctx *ctx, int count, const double *x, const double *max_term,
+                            const int32_t *estimate, double *num, double *den) {
+    if (!ctx || count < 0 || (count && (!x || !max_term || !estimate || !num || !den)))
+        return fail(ctx, MIPX_EINVAL, "mipx_get_fraction_batch: bad argument");
+    if (count == 0) return MIPX_OK;
+    for (int i = 0; i < count; i++)
+        if (estimate[i] < 0 || estimate[i] > 2 || !(max_term[i] > 0))
+            return fail(ctx, MIPX_EINVAL, "mipx_get_fraction_batch: estimate must be 0..2, max_term positive");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t N = (size_t)count;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_x = carve(N * 8), o_mt = carve(N * 8), o_es = carve(N * 4), o_nu = carve(N * 8), o_de = carve(N * 8);
+    if (off > ctx->scratch_bytes) {
+        if (ctx->scratch) (void)hipFree(ctx->scratch);
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->scratch, off));
+        ctx->scratch_bytes = off;
+    }
+    char *base = (char *)ctx->scratch;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_x, x, N * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_mt, max_term, N * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_es, estimate, N * 4, hipMemcpyHostToDevice, st));
+    mipx::FractionArgs g;
+    g.count = count;
+    g.x = (const double *)(base + o_x); g.max_term = (const double *)(base + o_mt);
+    g.estimate = (const int32_t *)(base + o_es);
+    g.num = (double *)(base + o_nu); g.den = (double *)(base + o_de);
+    hipLaunchKernelGGL(mipx::get_fraction_batch, dim3((count + 255) / 256), dim3(256), 0, st, g);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(num, base + o_nu, N * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(den, base + o_de, N * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return MIPX_OK;
+}
+
 int mipx_dev_alloc(mipx_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return MIPX_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -626,7 +626,11 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
                     pc_update(t, nd.b_idx, nd.b_dir, status[k], obj[k], nd.dual_bound, vc);
                     changed = true;
                 }
-                if (dived(k)) {  // the dive child: the update for the branch that made it
+                // the dive child: the update for the branch that made it -- like any node only if its
+                // own LP is feasible (pseudo_cost.py:42-43), and only where step 4 will accept the
+                // dive (the reference never creates that child under a pruned or integral parent)
+                const bool child_feasible = S.dive && (status[B + k] == 0 || status[B + k] == 2);
+                if (dived(k) && child_feasible && obj[k] < t->primal && !mipf[k]) {
                     const double vc = ddir[k] == 0 ? dval[k] - std::floor(dval[k]) : std::ceil(dval[k]) - dval[k];
                     pc_update(t, dvar[k], ddir[k], status[B + k], obj[B + k], obj[k], vc);
                     changed = true;

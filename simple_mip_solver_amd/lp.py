@@ -10,6 +10,8 @@ Also here: a few lines of modelling sugar (`CyLPArray`, `x = lp.addVariable('x',
 `lp += l <= x <= u`, `lp.addConstraint(pi * x >= pi0, name)`) so that code and tests written
 against the reference's cylp idioms (base_node.py:459-460, :594-606) read the same.
 """
+from collections import OrderedDict
+
 import numpy as np
 
 COIN_INFINITY = 1.7976931348623157e308  # what CyClpSimplex.getCoinInfinity() reports
@@ -188,10 +190,12 @@ class LPBackend:
 class HipBackend(LPBackend):
     """Sends the solve to libmipx.so on the MI355X (no fallback)."""
 
+    MAX_RESIDENT_ROWSETS = 64
+
     def __init__(self, device=None):
         self._device = device
         self._ctx = None
-        self._problems = {}
+        self._problems = OrderedDict()   # row-set key -> resident Problem, least recently used first
 
     def _context(self):
         if self._ctx is None:
@@ -203,11 +207,18 @@ class HipBackend(LPBackend):
     def _problem(self, A, b, c, cache_key):
         from simple_mip_solver_amd import _ffi
         p = self._problems.get(cache_key)
-        if p is None:
-            if len(self._problems) > 64:  # keep a bounded number of row sets resident
-                self._problems.pop(next(iter(self._problems))).close()
-            p = _ffi.Problem(self._context(), A, b, c)
-            self._problems[cache_key] = p
+        if p is not None:
+            self._problems.move_to_end(cache_key)
+            return p
+        # A bounded number of row sets stays resident.  Eviction only drops the cache's reference:
+        # a live _ffi.Tree (BranchAndBound._native) or an LP in flight may still hold the Problem's
+        # raw handle, so the device buffers are freed by Problem.__del__ once nobody refers to it,
+        # never by an explicit close() here.  Least recently used goes first (the root row set of
+        # a tree is hit by every cut-free node and must outlive the per-round row sets).
+        while len(self._problems) >= self.MAX_RESIDENT_ROWSETS:
+            self._problems.popitem(last=False)
+        p = _ffi.Problem(self._context(), A, b, c)
+        self._problems[cache_key] = p
         return p
 
     def solve(self, A, b, c, l, u, vstat, max_iter, cache_key):
