@@ -110,6 +110,22 @@ int mipx_lp_solve_batch(mipx_problem *p, int batch, const double *l, const doubl
                         int32_t *npivots);
 
 /*
+ * The same for nodes that carry cut rows (the kernel variant the frontier engine's cut rounds run;
+ * exposed for the parity tests): node k solves  min c'x, A x >= b, cut rows cut_ids[k*kc + i] (i <
+ * ncut[k]) of the store (cut_pi: ncuts_total x n, cut_pi0), l_k <= x <= u_k -- base_node.py:459-460
+ * appends a selected cut as one more `>=` row.  Results are those of mipx_lp_solve_batch on the
+ * problem with the node's rows materialised.  vstat_in / vstat_out have n + m + kc entries per node
+ * (structurals, shared rows, cut rows), y has m + kc.  kc <= 64, m + kc <= 192, n <= 256.
+ * HOST pointers.
+ */
+int mipx_lp_solve_batch_cuts(mipx_problem *p, int batch, const double *l, const double *u,
+                             const int8_t *vstat_in, int ncuts_total, const double *cut_pi,
+                             const double *cut_pi0, int kc, const int32_t *ncut,
+                             const int32_t *cut_ids, int max_iter, int32_t *status, double *obj,
+                             double *x, double *y, int8_t *vstat_out, int32_t *iters,
+                             int32_t *npivots);
+
+/*
  * Device-resident variant (inputs and outputs already in HBM; nothing crosses PCIe).
  * Pointers are DEVICE pointers obtained from mipx_dev_alloc.  Asynchronous on the context
  * stream; call mipx_ctx_sync before reading results back.
@@ -252,6 +268,42 @@ typedef struct mipx_tree_stats {
 int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const double *l,
                      const double *u, int branch_rule, int search_rule, int strong_branch_iters,
                      int max_batch, int64_t pool_capacity, mipx_tree **out);
+/*
+ * The same with Gomory cut rounds inside the engine (BASELINE config C4): every evaluated node runs
+ * BaseNode._base_bound's loop (base_node.py:137-230) -- LP, then while fractional and progressing at
+ * most max_cut_generation_iterations rounds of: drop cuts with zero dual (:326-341), GMI cuts from
+ * the tableau of its basis with safe rounding (:365-385, :468-511), selection (:387-466), re-solve,
+ * stall test (:320-324).  Cut rows live in an append-only store in HBM (n + 1 doubles per cut); a
+ * node record carries the ids of its rows (at most max_cuts_per_node <= 64), children and
+ * strong-branching probes inherit them with the basis (base_node.py:602-608).  The LP of a node with
+ * k cuts is exactly the (m + k)-row LP: same arithmetic as mipx_lp_solve_batch on the materialised
+ * rows.  Register-tile shapes only: m + max_cuts_per_node <= 192, n <= 256.  cuts == NULL: no cut
+ * rounds (mipx_tree_create).  The in-place dive and mipx_tree_reanchor are not available with cuts.
+ */
+typedef struct mipx_cut_params {
+    int32_t max_cut_generation_iterations; /* tolerance.max_cut_generation_iterations (10) */
+    int32_t max_nonzero_coefs;             /* _select_cuts keyword (base_node.py:387) */
+    int32_t max_cuts_per_node;             /* <= 64; 0 = 64.  A node whose list is full adds no more (counted as dropped) */
+    int32_t exact_tableau;                 /* 1: the GMI tableau is refactored from the slack basis like the
+                                              per-node path (node-for-node parity); 0: anchors allowed */
+    double cutting_plane_progress_tolerance; /* base_node.py:292 (1e-4) */
+    double min_cut_depth;                  /* _select_cuts keyword (1e-8) */
+    double cos_parallel;                   /* cos(radians(parallel_cut_tolerance)) */
+    double max_abs_coef;                   /* max_relative_cut_term_ratio * node.max_term (max |A|) */
+    double max_term;                       /* tolerance.max_term (1e3): largest numerator / denominator */
+    double max_dual_bound;                 /* _base_bound keyword (+inf) */
+    int64_t store_capacity;                /* cuts the store can hold; 0 = 1 << 20 */
+} mipx_cut_params;
+int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, const double *l,
+                        const double *u, int branch_rule, int search_rule, int strong_branch_iters,
+                        int max_batch, int64_t pool_capacity, const mipx_cut_params *cuts,
+                        mipx_tree **out);
+/* Running totals of the cut loop over every evaluated node, in the order BaseNode._base_bound returns
+ * them (base_node.py:218-226): total_cut_generation_iterations, total_iterations_gmic_created,
+ * total_number_gmic_created, total_iterations_gmic_added, total_number_gmic_added,
+ * total_iterations_gmic_removed, total_number_gmic_removed; out[7] = cuts dropped for lack of room
+ * (a full node list, pool slab or store: 0 unless a capacity was set too small). */
+int mipx_tree_cut_stats(mipx_tree *t, int64_t out[8]);
 void mipx_tree_destroy(mipx_tree *t);
 /* Run or continue the search (re-entrant like BranchAndBound.solve).  Limits <= 0 mean none.
  * frontier_batch = 1 reproduces the reference's node order exactly. */

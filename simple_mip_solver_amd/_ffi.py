@@ -20,7 +20,8 @@ SYMBOLS = [
     'mipx_last_error', 'mipx_ctx_sync', 'mipx_problem_create', 'mipx_problem_destroy', 'mipx_problem_set_anchor',
     'mipx_tree_set_anchor_mode',
     'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_lp_solve_multi', 'mipx_gomory_batch', 'mipx_cut_select_batch',
-    'mipx_safe_cut_batch', 'mipx_get_fraction_batch', 'mipx_dev_alloc', 'mipx_dev_free',
+    'mipx_safe_cut_batch', 'mipx_get_fraction_batch', 'mipx_lp_solve_batch_cuts', 'mipx_tree_create_ex',
+    'mipx_tree_cut_stats', 'mipx_dev_alloc', 'mipx_dev_free',
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
     'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
@@ -54,6 +55,19 @@ class TreeStats(C.Structure):
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
+
+class CutParams(C.Structure):
+    """mipx_cut_params (include/mipx.h)."""
+    _fields_ = [('max_cut_generation_iterations', C.c_int32), ('max_nonzero_coefs', C.c_int32),
+                ('max_cuts_per_node', C.c_int32), ('exact_tableau', C.c_int32),
+                ('cutting_plane_progress_tolerance', C.c_double), ('min_cut_depth', C.c_double),
+                ('cos_parallel', C.c_double), ('max_abs_coef', C.c_double), ('max_term', C.c_double),
+                ('max_dual_bound', C.c_double), ('store_capacity', C.c_int64)]
+
+
+CUT_TOTAL_KEYS = ('total_cut_generation_iterations', 'total_iterations_gmic_created',
+                  'total_number_gmic_created', 'total_iterations_gmic_added', 'total_number_gmic_added',
+                  'total_iterations_gmic_removed', 'total_number_gmic_removed')
 
 TREE_STATUS = {0: 'unsolved', 1: 'optimal', 2: 'infeasible', 3: 'unbounded',
                4: 'stopped on iterations or time'}
@@ -305,6 +319,40 @@ class Problem:
         self.ctx.check(rc, 'mipx_lp_solve_batch')
         return dict(status=status, obj=obj, x=x, y=y, vstat=vout, iters=iters, npivots=npiv)
 
+    def solve_batch_cuts(self, l, u, vstat, cut_pi, cut_pi0, cut_lists, max_iter=0, kc=64):
+        """Node LPs with per-node cut rows (mipx_lp_solve_batch_cuts): cut_lists[k] = ids (rows of
+        cut_pi / cut_pi0) node k carries after the m shared rows.  vstat rows: n + m + len(cut_lists[k])
+        codes each (a list of arrays) or None.  Returns dict like solve_batch; y and vstat are lists of
+        per-node arrays over the node's own rows."""
+        n, m = self.n, self.m
+        l = np.ascontiguousarray(l, dtype=np.float64).reshape(-1, n)
+        B = l.shape[0]
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(B, n)
+        cut_pi = np.ascontiguousarray(cut_pi, dtype=np.float64).reshape(-1, n)
+        cut_pi0 = np.ascontiguousarray(cut_pi0, dtype=np.float64).reshape(-1)
+        ncut = np.array([len(c) for c in cut_lists], np.int32)
+        ids = np.zeros((B, kc), np.int32)
+        for k, c in enumerate(cut_lists):
+            ids[k, :len(c)] = c
+        M = m + kc
+        vin = None
+        if vstat is not None:
+            vin = np.zeros((B, n + M), np.int8)
+            for k in range(B):
+                vin[k, :n + m + ncut[k]] = vstat[k]
+        status = np.zeros(B, np.int32); obj = np.zeros(B); x = np.zeros((B, n)); y = np.zeros((B, M))
+        vout = np.zeros((B, n + M), np.int8); iters = np.zeros(B, np.int32); npiv = np.zeros(B, np.int32)
+        L = lib()
+        L.mipx_lp_solve_batch_cuts.argtypes = [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp,
+                                               C.c_int] + [_vp] * 7
+        rc = L.mipx_lp_solve_batch_cuts(self._h, B, _ptr(l), _ptr(u), _ptr(vin), len(cut_pi0), _ptr(cut_pi),
+                                        _ptr(cut_pi0), kc, _ptr(ncut), _ptr(ids), int(max_iter), _ptr(status),
+                                        _ptr(obj), _ptr(x), _ptr(y), _ptr(vout), _ptr(iters), _ptr(npiv))
+        self.ctx.check(rc, 'mipx_lp_solve_batch_cuts')
+        return dict(status=status, obj=obj, x=x, iters=iters, npivots=npiv,
+                    y=[y[k, :m + ncut[k]].copy() for k in range(B)],
+                    vstat=[vout[k, :n + m + ncut[k]].copy() for k in range(B)])
+
     def dive_batch(self, l, u, vstat, rule, integer_indices, cost_l=None, cost_r=None, has_entry=None,
                    cutoff=float('inf'), max_iter=0):
         """Node LPs with the in-place dive (mipx_lp_dive_batch); arrays of 2 * batch rows (nodes,
@@ -378,7 +426,9 @@ class Tree:
 
     def __init__(self, problem, integer_indices, l, u, branch_rule='most fractional',
                  search_rule='best first', strong_branch_iters=5, max_batch=1,
-                 pool_capacity=1 << 16):
+                 pool_capacity=1 << 16, cut_params=None):
+        """cut_params: None (no cut rounds) or a dict of mipx_cut_params fields -- Gomory cut rounds
+        run inside the engine (mipx_tree_create_ex)."""
         self.problem = problem
         ints = np.ascontiguousarray(integer_indices, dtype=np.int32)
         l = np.ascontiguousarray(l, dtype=np.float64).reshape(problem.n)
@@ -386,10 +436,23 @@ class Tree:
         rule = {'most fractional': 0, 'pseudo cost': 1}[branch_rule]
         search = {'best first': 0, 'depth first': 1}[search_rule]
         h = _vp()
-        rc = lib().mipx_tree_create(problem._h, _ptr(ints), len(ints), _ptr(l), _ptr(u), rule,
-                                    search, int(strong_branch_iters), int(max_batch),
-                                    int(pool_capacity), C.byref(h))
-        problem.ctx.check(rc, 'mipx_tree_create')
+        L = lib()
+        L.mipx_tree_create_ex.argtypes = [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int64, C.POINTER(CutParams), C.POINTER(_vp)]
+        cp = None
+        if cut_params is not None:
+            cp = CutParams(max_cut_generation_iterations=10, max_nonzero_coefs=1000000, max_cuts_per_node=0,
+                           exact_tableau=1, cutting_plane_progress_tolerance=1e-4, min_cut_depth=1e-8,
+                           cos_parallel=0.984807753012208, max_abs_coef=1e6, max_term=1e3,
+                           max_dual_bound=float('inf'), store_capacity=0)
+            for key, value in cut_params.items():
+                assert hasattr(cp, key), f'unknown cut parameter {key}'
+                setattr(cp, key, value)
+        rc = L.mipx_tree_create_ex(problem._h, _ptr(ints), len(ints), _ptr(l), _ptr(u), rule,
+                                   search, int(strong_branch_iters), int(max_batch),
+                                   int(pool_capacity), None if cp is None else C.byref(cp), C.byref(h))
+        problem.ctx.check(rc, 'mipx_tree_create_ex')
+        self.cuts = cp is not None
         self._h = h
         self.max_batch = int(max_batch)
 
@@ -461,6 +524,16 @@ class Tree:
             self._hook = proto(trampoline)  # keep the thunk alive as long as it is installed
             rc = L.mipx_tree_set_step_hook(self._h, self._hook, None, int(every_steps))
         self.problem.ctx.check(rc, 'mipx_tree_set_step_hook')
+
+    def cut_stats(self):
+        """The running GMIC totals of BaseNode._base_bound over every evaluated node (+ 'dropped')."""
+        out = (C.c_int64 * 8)()
+        L = lib()
+        L.mipx_tree_cut_stats.argtypes = [_vp, _vp]
+        self.problem.ctx.check(L.mipx_tree_cut_stats(self._h, out), 'mipx_tree_cut_stats')
+        d = {k: int(out[i]) for i, k in enumerate(CUT_TOTAL_KEYS)}
+        d['dropped'] = int(out[7])
+        return d
 
     def stats(self):
         st = TreeStats()

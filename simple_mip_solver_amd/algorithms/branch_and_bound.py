@@ -130,8 +130,10 @@ class BranchAndBound(BaseAlgorithm):
         frontier_batch (extension, default None = the reference's one-node-at-a-time Python
         loop): run the whole search in the native frontier engine (mipx_tree_*), evaluating that
         many open nodes per GPU step with node records resident in HBM.  Only for the stock node
-        classes, the default queue and gomory_cuts=False; frontier_batch=1 keeps the reference's
-        exact node order.  In this mode `tree` holds only the root (nodes live on the device).
+        classes and the default queue; frontier_batch=1 keeps the reference's exact node order.
+        With gomory_cuts=True (the reference's default, base_node.py:365) every node runs the cut
+        rounds of BaseNode._base_bound inside the engine (register-tile shapes: m + 64 <= 192 rows,
+        n <= 256; no dive then).  In this mode `tree` holds only the root (nodes live on the device).
         anchor / dive (default: on for frontier_batch > 1, register-tile shapes): warm starts
         refactor from the root's optimal tableau instead of the slack basis; the workgroup that
         solved a node also solves one child on the tableau it holds (same optimum, another node
@@ -144,12 +146,13 @@ class BranchAndBound(BaseAlgorithm):
             assert node_queue is None, 'frontier_batch needs the default node queue'
             assert Node in _NATIVE_NODES, \
                 'frontier_batch is only available for the stock node classes'
-            assert kwargs.get('gomory_cuts') is False, \
-                'frontier_batch needs gomory_cuts=False (cut rounds run on the per-node path)'
+            assert isinstance(kwargs.get('gomory_cuts', True), bool), 'gomory_cuts is boolean'
         self.frontier_batch = frontier_batch
         batched = frontier_batch is not None and frontier_batch > 1
+        native_cuts = frontier_batch is not None and kwargs.get('gomory_cuts', True)
         self._anchor = batched if anchor is None else bool(anchor)
-        self._dive = batched if dive is None else bool(dive)
+        self._dive = (batched and not native_cuts) if dive is None else bool(dive)
+        assert not (self._dive and native_cuts), 'dive is not available with gomory_cuts=True'
         assert not (self._dive and not batched), 'dive needs frontier_batch > 1'
         self._pool_capacity = pool_capacity
         node_queue = node_queue or PriorityQueue()
@@ -241,6 +244,7 @@ class BranchAndBound(BaseAlgorithm):
         from simple_mip_solver_amd import _ffi
         from simple_mip_solver_amd.lp import get_backend, HipBackend
         if self._native is None:
+            self._native_totals0 = {k: self._kwargs.get(k, 0) for k in _ffi.CUT_TOTAL_KEYS}
             backend = get_backend()
             assert isinstance(backend, HipBackend), 'frontier_batch needs the HIP backend'
             lp = self.root_node.lp
@@ -248,12 +252,31 @@ class BranchAndBound(BaseAlgorithm):
             problem = backend._problem(rs.A, rs.b, rs.c, rs.key)
             l, u = lp._bounds()
             pseudo = issubclass(self._Node, PseudoCostBranchNode)
+            cut_params = None
+            if self._kwargs.get('gomory_cuts', True):
+                # the keyword defaults of BaseNode._base_bound / _cut_generation_iteration / _select_cuts
+                # (base_node.py:137, :292, :387), overridable through **kwargs as there
+                from math import cos, radians
+                from simple_mip_solver_amd.utils import tolerance as tol
+                kw = self._kwargs
+                rounds = kw.get('max_cut_generation_iterations', tol.max_cut_generation_iterations)
+                cut_params = dict(
+                    max_cut_generation_iterations=int(min(rounds, 2 ** 31 - 1)),
+                    max_nonzero_coefs=int(min(kw.get('max_nonzero_coefs', tol.max_nonzero_coefs), 2 ** 31 - 1)),
+                    cutting_plane_progress_tolerance=kw.get('cutting_plane_progress_tolerance',
+                                                            tol.cutting_plane_progress_tolerance),
+                    min_cut_depth=kw.get('min_cut_depth', tol.min_cut_depth),
+                    cos_parallel=cos(radians(kw.get('parallel_cut_tolerance', tol.parallel_cut_tolerance))),
+                    max_abs_coef=kw.get('max_relative_cut_term_ratio', tol.max_relative_cut_term_ratio) *
+                    float(self.root_node.max_term),
+                    max_term=tol.max_term, max_dual_bound=kw.get('max_dual_bound', INF),
+                    exact_tableau=0 if self._anchor else 1)
             self._native = _ffi.Tree(
                 problem, self.model.integerIndices, l, u,
                 branch_rule='pseudo cost' if pseudo else 'most fractional',
                 search_rule=self.root_node.search_method,
                 strong_branch_iters=self._kwargs.get('strong_branch_iters', 5),
-                max_batch=self.frontier_batch, pool_capacity=self._pool_capacity)
+                max_batch=self.frontier_batch, pool_capacity=self._pool_capacity, cut_params=cut_params)
             if self.primal_bound < INF:
                 self._native.set_primal_bound(self.primal_bound)
             table = self._kwargs.get('pseudo_costs')
@@ -291,6 +314,11 @@ class BranchAndBound(BaseAlgorithm):
         self._kwargs['next_node_idx'] = st['created_nodes']
         if issubclass(self._Node, PseudoCostBranchNode):
             self._kwargs['pseudo_costs'] = self._native.pseudo_costs()
+        if self._native.cuts:   # the running GMIC totals bound() threads through the kwargs
+            totals = self._native.cut_stats()
+            self._native_cuts_dropped = totals.pop('dropped')
+            for key, value in totals.items():
+                self._kwargs[key] = self._native_totals0.get(key, 0) + value
 
     def _evaluate_node(self, node):
         """Bound the node unless its inherited bound already prunes it; record an incumbent or

@@ -214,6 +214,21 @@ struct GomoryArgs {
     double *pi, *pi0;             // batch x m x n, batch x m : raw GMI cuts  pi.x >= pi0
     double *safe_pi, *safe_pi0;   // rounded ('over' coefficients, 'under' right-hand side)
     int chunks = 1;               // workgroups per node: cut c of a node is worked out by workgroup c % chunks
+    // ---- frontier engine with cut rounds (all optional) ------------------------------------------
+    // per-node cut rows, as in LpArgs: node k has m + ncut[k] rows, row m + i = cut cut_ids[k * cut_stride + i]
+    const int32_t *ncut = nullptr, *cut_ids = nullptr;
+    const double *cut_pi = nullptr, *cut_pi0 = nullptr;
+    int cut_stride = 0;
+    int mstride = 0;              // rows allotted per node in T / idx / row_idx (0: m)
+    const int8_t *vstat = nullptr;  // batch x (n + mstride): no cuts unless exactly m + ncut entries are basic
+                                    //   (the reference's tableau is None then, base_node.py:518-519)
+    int clip_x = 0;               // read x as max(x, 0) (base_node.py:310)
+    const int32_t *active = nullptr;  // skip nodes with active[k] == 0
+    // a node's rounded cuts go to its slab of the engine's cut pool instead of safe_pi: cut c to row
+    // slab_n[k] + c of the slab_rows rows that start at row k * slab_rows of slab_pi / slab_pi0
+    double *slab_pi = nullptr, *slab_pi0 = nullptr;
+    const int32_t *slab_n = nullptr;
+    int slab_rows = 0;
 };
 
 template <int NT>
@@ -223,21 +238,41 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
     // path: one) `chunks` workgroups share them, every one walking the same row order
     const int node = blockIdx.x / g.chunks, chunk = blockIdx.x % g.chunks;
     if (node >= g.batch) return;
+    if (g.active != nullptr && g.active[node] == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = g.m, n = g.n;
+    const int m0 = g.m, n = g.n;
+    const int kcut = g.ncut ? g.ncut[node] : 0;
+    const int m = m0 + kcut;                       // this node's rows: the shared ones, then its cuts
+    const int ms = g.mstride ? g.mstride : m0;     // rows allotted per node in the strided arrays
+    const int32_t *cids = g.ncut ? g.cut_ids + (size_t)node * g.cut_stride : nullptr;
     const double INF = __builtin_huge_val();
-    // dynamic LDS carve: pi_var[n] | ps[m] | red[64] | order[m] | basic flag not needed
+    // dynamic LDS carve (sized for ms rows): pi_var[n] | ps[ms] | red[64] | order[ms] | bvar[ms] | nvar[n]
     double *pi_var = (double *)smem_raw;
     double *ps = pi_var + n;
-    double *red = ps + m;
+    double *red = ps + ms;
     int *order = (int *)(red + 64);   // order[rank] = tableau row
-    int *bvar_s = order + m;
-    int *nvar_s = bvar_s + m;
-    const int32_t *idx = g.idx + (size_t)node * (2 * n + m);
-    const double *T = g.T + (size_t)node * m * n;
+    int *bvar_s = order + ms;
+    int *nvar_s = bvar_s + ms;
+    const int32_t *idx = g.idx + (size_t)node * (2 * n + ms);
+    const double *T = g.T + (size_t)node * ms * n;
     const double *x = g.x + (size_t)node * n;
     for (int j = tid; j < n; j += NT) nvar_s[j] = idx[j];
     for (int i = tid; i < m; i += NT) bvar_s[i] = idx[n + i];
+    if (g.vstat != nullptr) {  // a basis that is not square gives no tableau, hence no cuts
+        const int8_t *vs = g.vstat + (size_t)node * (n + ms);
+        int cnt = 0;
+        for (int v = tid; v < n + m; v += NT) cnt += vs[v] == 1;
+        for (int h = 32; h >= 1; h >>= 1) cnt += __shfl_down(cnt, h, 64);
+        if (lane == 0) red[wave] = (double)cnt;
+        __syncthreads();
+        int total = 0;
+        for (int w = 0; w < NT / 64; w++) total += (int)red[w];
+        __syncthreads();
+        if (total != m) {
+            if (tid == 0 && chunk == 0) g.ncuts[node] = 0;
+            return;
+        }
+    }
     __syncthreads();
     // rank of each basic variable among the basics (row order of inv(A_B) in the reference)
     for (int i = tid; i < m; i += NT) {
@@ -254,7 +289,7 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
         bool gen = v < n && g.is_int[v < n ? v : 0];
         double f0 = 0.0;
         if (gen) {
-            const double xv = x[v];
+            const double xv = g.clip_x ? fmax(x[v], 0.0) : x[v];
             const double fl = floor(xv), ce = ceil(xv);
             gen = fmin(xv - fl, ce - xv) > kVarEpsCut;
             f0 = xv - fl;
@@ -282,23 +317,25 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
             }
         }
         __syncthreads();
-        // coefs = pi + A' ps, accumulated row by row (the order of the reference's sparse product)
-        double *out_pi = g.pi + ((size_t)node * m + ncuts) * n;
+        // coefs = pi + A' ps, accumulated row by row (the order of the reference's sparse product);
+        // the node's cut rows follow the shared ones
+        double *out_pi = g.pi ? g.pi + ((size_t)node * ms + ncuts) * n : nullptr;
         for (int var = tid; var < n; var += NT) {
             double acc = 0.0;
             // (same order of additions; the loads of 16 rows are issued before the first is consumed:
             // the plain loop paid one L2 latency per row, 20 us per cut at m = 128)
             int i = 0;
-            for (; i + 16 <= m; i += 16) {
+            for (; i + 16 <= m0; i += 16) {
                 double a[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++) a[k] = g.A[(size_t)(i + k) * n + var];
 #pragma unroll
                 for (int k = 0; k < 16; k++) acc = acc + a[k] * ps[i + k];
             }
-            for (; i < m; i++) acc = acc + g.A[(size_t)i * n + var] * ps[i];
+            for (; i < m0; i++) acc = acc + g.A[(size_t)i * n + var] * ps[i];
+            for (; i < m; i++) acc = acc + g.cut_pi[(size_t)cids[i - m0] * n + var] * ps[i];
             const double coef = pi_var[var] + acc;
-            out_pi[var] = coef;
+            if (out_pi) out_pi[var] = coef;
             pi_var[var] = coef;   // keep for the rounding below
         }
         // rhs = 1 + ps . b with a fold-in-half tree over the next power of two (wave 0)
@@ -307,8 +344,9 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
             while (m2 < m) m2 <<= 1;
             // each lane folds its strided elements first (j and j + m2/2 ... down to 64 lanes)
             double part = 0.0;
+            auto rhs_of = [&](int j) { return j < m0 ? g.b[j] : g.cut_pi0[cids[j - m0]]; };
             if (m2 <= 64) {
-                part = lane < m ? ps[lane] * g.b[lane] : 0.0;
+                part = lane < m ? ps[lane] * rhs_of(lane) : 0.0;
                 for (int h = m2 / 2; h >= 1; h >>= 1) part = part + __shfl_down(part, h, 64);
             } else {
                 // lane holds elements lane + 64*k: fold the k levels in registers, then across lanes
@@ -316,7 +354,7 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
                 const int per = m2 / 64;  // <= 16 for m <= 1024
                 for (int k = 0; k < 16; k++) {
                     const int j = lane + 64 * k;
-                    e[k] = (k < per && j < m) ? ps[j] * g.b[j] : 0.0;
+                    e[k] = (k < per && j < m) ? ps[j] * rhs_of(j) : 0.0;
                 }
                 for (int h = per / 2; h >= 1; h >>= 1)
                     for (int k = 0; k < h; k++) e[k] = e[k] + e[k + h];
@@ -325,8 +363,8 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
             }
             if (lane == 0) {
                 const double rhs = 1.0 + part;
-                g.pi0[(size_t)node * m + ncuts] = rhs;
-                g.row_idx[(size_t)node * m + ncuts] = rank;
+                if (g.pi0) g.pi0[(size_t)node * ms + ncuts] = rhs;
+                if (g.row_idx) g.row_idx[(size_t)node * ms + ncuts] = rank;
                 red[0] = rhs;
             }
         }
@@ -348,10 +386,21 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
         double scale = INF;
         bool nonzero = false;
         for (int wv = 0; wv < NT / 64; wv++) { scale = fmin(scale, red[1 + wv]); nonzero |= red[33 + wv] != 0.0; }
-        double *out_sp = g.safe_pi + ((size_t)node * m + ncuts) * n;
+        // where the rounded cut goes: row ncuts of the node's block of safe_pi, or (engine) the next
+        // free row of the node's pool slab; a full slab drops the cut
+        double *out_sp, *out_s0;
+        if (g.slab_pi != nullptr) {
+            const int row = g.slab_n[node] + ncuts;
+            if (row >= g.slab_rows) { ncuts++; continue; }   // (uniform)
+            out_sp = g.slab_pi + ((size_t)node * g.slab_rows + row) * n;
+            out_s0 = g.slab_pi0 + (size_t)node * g.slab_rows + row;
+        } else {
+            out_sp = g.safe_pi + ((size_t)node * ms + ncuts) * n;
+            out_s0 = g.safe_pi0 + (size_t)node * ms + ncuts;
+        }
         if (!nonzero) {
             for (int var = tid; var < n; var += NT) out_sp[var] = pi_var[var];
-            if (tid == 0) g.safe_pi0[(size_t)node * m + ncuts] = red[0];
+            if (tid == 0) *out_s0 = red[0];
         } else {
             for (int var = tid; var < n; var += NT) {
                 const double coef = pi_var[var] * scale;
@@ -362,12 +411,14 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
             if (tid == 0) {
                 double n0, d0;
                 get_fraction_dev(red[0] * scale, 1e3, kEstUnder, n0, d0);
-                g.safe_pi0[(size_t)node * m + ncuts] = n0 / d0;
+                *out_s0 = n0 / d0;
             }
         }
         __syncthreads();
         ncuts++;
     }
+    // (engine: the new slab rows join the node's pool in pool_append, after every workgroup of the
+    // node is done with slab_n)
     if (tid == 0 && chunk == 0) g.ncuts[node] = ncuts;
 }
 
@@ -390,7 +441,12 @@ struct SelectArgs {
     int32_t *nadded;              // batch
     int32_t *added;               // batch x kmax: pool positions in the order they are added
     int32_t *terminator;          // batch: 0 none, 1 'no cuts', 2 'no improving cuts', 3 'no sufficient cuts'
-    double *depth;                // batch x kmax (NaN-free: +inf for cuts that are not candidates)
+    double *depth;                // batch x kmax (NaN-free: +inf for cuts that are not candidates); may be null
+    // frontier engine (optional): pool entry k of a node is row pool_list[node * kmax + k] of the
+    // node's kmax-row slab of pi / pi0 (slab rows are never moved; the list keeps the pool's order)
+    const int32_t *pool_list = nullptr;
+    int clip_x = 0;               // read x as max(x, 0) (base_node.py:310)
+    const int32_t *active = nullptr;  // skip nodes with active[k] == 0
 };
 
 // fold-in-half sum of f(j) over j < n2 (power of two, >= 64) by one wave; result in every lane
@@ -411,9 +467,12 @@ __global__ __launch_bounds__(256) void select_cuts(SelectArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int node = blockIdx.x;
     if (node >= g.batch) return;
+    if (g.active != nullptr && g.active[node] == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = g.n, K = g.npool[node];
     const double INF = __builtin_huge_val();
+    const int32_t *plist = g.pool_list ? g.pool_list + (size_t)node * g.kmax : nullptr;
+    auto row_of = [&](int k) { return plist ? plist[k] : k; };
     double *dep = (double *)smem_raw;   // K
     double *nrm = dep + g.kmax;         // K
     double *mab = nrm + g.kmax;         // K
@@ -426,7 +485,7 @@ __global__ __launch_bounds__(256) void select_cuts(SelectArgs g) {
     const double *x = g.x + (size_t)node * n;
     // per-cut statistics, one wave per cut
     for (int k = wave; k < K; k += 4) {
-        const double *pk = P + (size_t)k * n;
+        const double *pk = P + (size_t)row_of(k) * n;
         int sup = 0;
         double mx = 0.0;
         for (int j = lane; j < n; j += 64) {
@@ -437,13 +496,13 @@ __global__ __launch_bounds__(256) void select_cuts(SelectArgs g) {
         for (int h = 32; h >= 1; h >>= 1) sup += __shfl_down(sup, h, 64);
         sup = __shfl(sup, 0, 64);
         mx = wave_max_f64(mx);
-        const double dot = wave_fold(n2, lane, [&](int j) { return j < n ? pk[j] * x[j] : 0.0; });
+        const double dot = wave_fold(n2, lane, [&](int j) { return j < n ? pk[j] * (g.clip_x ? fmax(x[j], 0.0) : x[j]) : 0.0; });
         const double sq = wave_fold(n2, lane, [&](int j) { return j < n ? pk[j] * pk[j] : 0.0; });
         if (lane == 0) {
             const double nr = sqrt(sq);
             nrm[k] = nr;
             mab[k] = mx;
-            dep[k] = (sup > 0 && sup <= g.max_nonzero_coefs) ? (dot - g.pi0[(size_t)node * g.kmax + k]) / nr : INF;
+            dep[k] = (sup > 0 && sup <= g.max_nonzero_coefs) ? (dot - g.pi0[(size_t)node * g.kmax + row_of(k)]) / nr : INF;
         }
     }
     __syncthreads();
@@ -470,13 +529,13 @@ __global__ __launch_bounds__(256) void select_cuts(SelectArgs g) {
         const int k = ord[c];
         if (dep[k] >= -g.min_cut_depth) break;
         if (mab[k] > g.max_abs_coef) continue;
-        const double *pk = P + (size_t)k * n;
+        const double *pk = P + (size_t)row_of(k) * n;
         // dot products with the added cuts: one wave per added cut
         __syncthreads();
         if (tid == 0) cnt[1] = 0;
         __syncthreads();
         for (int a = wave; a < nadd; a += 4) {
-            const double *pa = P + (size_t)add[a] * n;
+            const double *pa = P + (size_t)row_of(add[a]) * n;
             const double dot = wave_fold(n2, lane, [&](int j) { return j < n ? pk[j] * pa[j] : 0.0; });
             if (lane == 0) {
                 double cs = dot / (nrm[k] * nrm[add[a]]);
@@ -492,7 +551,7 @@ __global__ __launch_bounds__(256) void select_cuts(SelectArgs g) {
     }
     __syncthreads();
     for (int k = tid; k < g.kmax; k += 256) {
-        g.depth[(size_t)node * g.kmax + k] = k < K ? dep[k] : INF;
+        if (g.depth) g.depth[(size_t)node * g.kmax + k] = k < K ? dep[k] : INF;
         if (k < nadd) g.added[(size_t)node * g.kmax + k] = add[k];
     }
     if (tid == 0) { g.nadded[node] = nadd; g.terminator[node] = term; }

@@ -90,6 +90,17 @@ struct LpArgs {
     double *dive_val = nullptr;
     int dive_preset = 0;            // 1: the kernel presets status[node + dive_off] = dive_var[node] = -1
     int32_t *zero16 = nullptr;      // optional: 4 words zeroed by workgroup 0 (K4's request counter)
+    // optional per-node cut rows (frontier engine with cut rounds; CUTS instantiation only): node k
+    // has ncut[k] rows appended to the m shared ones, row m + i being cut cut_ids[k * cut_stride + i]
+    // of the cut store (cut_pi: n doubles per cut, cut_pi0: its right-hand side; pi.x >= pi0 like
+    // every row, base_node.py:459-460).  The node's LP then is exactly the LP of its m + ncut rows:
+    // same arithmetic as a problem with those rows materialised.  mstride = rows allotted per node
+    // in vstat_in / vstat_out (n + mstride entries per node), y and the dbg_* dumps.  Indexed by
+    // batch position; with vstat_by_node the warm-start basis is too (l, u still through slot).
+    const int32_t *ncut = nullptr, *cut_ids = nullptr;
+    const double *cut_pi = nullptr, *cut_pi0 = nullptr;
+    int cut_stride = 0, mstride = 0, vstat_by_node = 0;
+    const int32_t *active = nullptr;  // optional: node k is skipped (nothing read or written) where active[k] == 0
 };
 
 constexpr double kVarEps = 1e-4;  // utils/tolerance.py:2 variable_epsilon
@@ -593,8 +604,9 @@ _Pragma("unroll")                                                               
 // control wave's copy never sees the register tableau (T is dead there), so the selections get
 // the registers the tableau would otherwise pin across them, and the tableau waves' copy carries
 // none of the control wave's borders.  Same source, same barriers.
-template <int NW, int R, int C, int MP, bool DIVE, bool CTL>
+template <int NW, int R, int C, int MP, bool DIVE, bool CTL, bool CUTS>
 __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R, C, MP> &s) {
+    static_assert(!(DIVE && CUTS), "the in-place dive runs before a node's cut rounds: not combined");
     constexpr int NT = 64 * (NW + 1);
     constexpr int NG = 4 * NW;          // row groups of the workgroup (4 per tableau wave)
     constexpr int NP = 16 * C;          // padded columns: 16 column lanes x C columns each
@@ -610,14 +622,21 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     const int tw = wave - 1;  // tableau wave index
     const int cl = lane & 15;                 // tableau lanes: column lane,
     const int grp = 4 * tw + (lane >> 4);     //   row group (rows grp + NG*ii)
-    const int m = g.m, n = g.n;
-    const int nv = n + m;
+    const int n = g.n;
     const double INF = __builtin_huge_val();
 
     // one workgroup per node LP (no grid-stride loop: a loop here makes the compiler hoist every
     // per-element predicate and address of the setup across the whole solve -> register spills)
     const int node = blockIdx.x;
     if (node >= g.batch) return;
+    if (CUTS && g.active != nullptr && g.active[node] == 0) return;  // (uniform over the workgroup)
+    // rows: the m shared ones, then this node's cuts
+    const int m0 = g.m;
+    const int kcut = CUTS ? __builtin_amdgcn_readfirstlane(g.ncut[node]) : 0;
+    const int m = m0 + kcut;
+    const int nv = n + m;
+    const int mstr = CUTS ? g.mstride : m;   // rows allotted per node in the strided arrays
+    const int32_t *cids = CUTS ? g.cut_ids + (size_t)node * g.cut_stride : nullptr;
 #ifdef MIPX_KPROF
     if (tid < 16) s.prof[tid] = 0;
     unsigned long long tprev = clock64();
@@ -635,14 +654,14 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     const double *gc = g.c + (size_t)node * g.c_stride;
     const double *lk = g.l + src * n;
     const double *uk = g.u + src * n;
-    const int8_t *vin = g.vstat_in ? g.vstat_in + src * nv : nullptr;
+    const int8_t *vin = g.vstat_in ? g.vstat_in + ((CUTS && g.vstat_by_node) ? (size_t)node : src) * (size_t)(n + mstr) : nullptr;
 
     // ---- 0. T = -A, beta0 = -b, d = c, slack basis (or the anchor's tableau state) -----------
     const int asel = (g.anchor_sel != nullptr && g.vstat_in != nullptr) ? __builtin_amdgcn_readfirstlane(g.anchor_sel[node]) : -1;
     const double *aT = asel >= 0 ? g.atab_T + (size_t)asel * ((size_t)m * n) : g.anchor_T;
     const double *avec = asel >= 0 ? g.atab_vec + (size_t)asel * (size_t)(n + 3 * m) : g.anchor_vec;
     const int32_t *aidx = asel >= 0 ? g.atab_idx + (size_t)asel * (size_t)(2 * n + m) : g.anchor_idx;
-    const bool anchored = aT != nullptr && vin != nullptr;
+    const bool anchored = aT != nullptr && vin != nullptr && kcut == 0;  // (an anchor has the shared rows only)
     const double sgn = anchored ? 1.0 : -1.0;
 #pragma unroll
     for (int ii = 0; ii < R; ii++) {
@@ -655,13 +674,21 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         // for HBM.  Every load is issued unconditionally from a clamped address (512 contiguous
         // bytes per wave instruction); sign and padding are fixed where the values are first used
         const double *tsrc = anchored ? aT : gA;
+        // row r of the node's LP: a shared row, or (CUTS) a row of the cut store
+        const double *rowp[R];
+#pragma unroll
+        for (int ii = 0; ii < R; ii++) {
+            const int r = min(MIPX_ROW(ii), m > 0 ? m - 1 : 0);
+            if (CUTS && r >= m0) rowp[ii] = g.cut_pi + (size_t)cids[r - m0] * n;
+            else rowp[ii] = tsrc + (size_t)r * n;
+        }
         if ((n & 1) == 0 && n >= 2) {  // adjacent column pairs as one 16-byte load
             int poff[C / 2];
 #pragma unroll
             for (int pp = 0; pp < C / 2; pp++) poff[pp] = min(32 * pp + 2 * cl, n - 2);
 #pragma unroll
             for (int ii = 0; ii < R; ii++) {
-                const double *arow = tsrc + (size_t)min(MIPX_ROW(ii), m > 0 ? m - 1 : 0) * n;
+                const double *arow = rowp[ii];
 #pragma unroll
                 for (int pp = 0; pp < C / 2; pp++) {
                     const double2 v = m > 0 ? *reinterpret_cast<const double2 *>(arow + poff[pp]) : double2{0.0, 0.0};
@@ -672,7 +699,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         } else {
 #pragma unroll
             for (int ii = 0; ii < R; ii++) {
-                const double *arow = tsrc + (size_t)min(MIPX_ROW(ii), m > 0 ? m - 1 : 0) * n;
+                const double *arow = rowp[ii];
 #pragma unroll
                 for (int jj = 0; jj < C; jj++) T[ii][jj] = m > 0 ? arow[min(MIPX_COL(jj), n - 1)] : 0.0;
             }
@@ -683,7 +710,9 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         // memory latency, not one per array); clamped addresses, the padding is fixed afterwards
         static_assert(NT >= NP + MP, "one staging element per thread");
         const int ic = min(tid, m > 0 ? m - 1 : 0), jc = min(tid, n - 1), vc = min(tid, nv - 1);
-        const double g_b0 = anchored ? avec[n + ic] : (m > 0 ? gb[ic] : 0.0);
+        double g_b0;
+        if (CUTS && ic >= m0) g_b0 = g.cut_pi0[cids[ic - m0]];
+        else g_b0 = anchored ? avec[n + ic] : (m > 0 ? gb[ic] : 0.0);
         const int g_bv = anchored ? aidx[n + ic] : n + ic;
         const double g_d = anchored ? avec[jc] : gc[jc];
         const int g_nv = anchored ? aidx[jc] : jc;
@@ -1189,7 +1218,8 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     int o_tid = tid, o_lane = lane, o_n = n, o_m = m;
     asm volatile("" : "+v"(o_tid), "+v"(o_lane), "+s"(o_n), "+s"(o_m));
     {
-    const int tid = o_tid, lane = o_lane, n = o_n, m = o_m, nv = o_n + o_m;
+    const int tid = o_tid, lane = o_lane, n = o_n, m = o_m;
+    const int ms = CUTS ? g.mstride : o_m;  // rows allotted per node in y / vstat_out / the dumps
     // ---- 4. outputs ---------------------------------------------------------------------------
 #ifdef MIPX_KPROF
     KPROF_MARK(6);
@@ -1235,21 +1265,21 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     if (g.x)
         for (int j = tid; j < n; j += NT) g.x[onode * n + j] = s.key[j];
     if (g.y) {
-        for (int i = tid; i < m; i += NT) g.y[onode * m + i] = 0.0;
+        for (int i = tid; i < m; i += NT) g.y[onode * ms + i] = 0.0;
         __syncthreads();
         for (int j = tid; j < n; j += NT)
-            if (s.nvar[j] >= n) g.y[onode * m + (s.nvar[j] - n)] = s.d[j];
+            if (s.nvar[j] >= n) g.y[onode * ms + (s.nvar[j] - n)] = s.d[j];
     }
     if (g.vstat_out) {
-        int8_t *vo = g.vstat_out + onode * nv;
+        int8_t *vo = g.vstat_out + onode * (size_t)(n + ms);
         for (int i = tid; i < m; i += NT) vo[s.bvar[i]] = 1;
         for (int j = tid; j < n; j += NT) vo[s.nvar[j]] = s.side[j] ? 2 : 3;
     }
     if (g.dbg_T && (node == 0 || g.dbg_all)) {
         const size_t k = g.dbg_all ? (size_t)node : 0;
-        double *dT = g.dbg_T + k * (size_t)m * n;
-        double *dvec = g.dbg_vec + k * (size_t)(n + 3 * m);
-        int32_t *didx = g.dbg_idx + k * (size_t)(2 * n + m);
+        double *dT = g.dbg_T + k * (size_t)ms * n;
+        double *dvec = g.dbg_vec + k * (size_t)(n + 3 * ms);
+        int32_t *didx = g.dbg_idx + k * (size_t)(2 * n + ms);
 #pragma unroll
         for (int ii = 0; ii < R; ii++) {
 #pragma unroll
@@ -1361,11 +1391,11 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     }
 }
 
-template <int NW, int R, int C, int MP, bool DIVE = false>
+template <int NW, int R, int C, int MP, bool DIVE = false, bool CUTS = false>
 __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
     __shared__ Smem<NW, R, C, MP> s;
-    if (threadIdx.x < 64) lp_dual_simplex_role<NW, R, C, MP, DIVE, true>(g, s);   // wave 0: control
-    else lp_dual_simplex_role<NW, R, C, MP, DIVE, false>(g, s);                   // tableau waves
+    if (threadIdx.x < 64) lp_dual_simplex_role<NW, R, C, MP, DIVE, true, CUTS>(g, s);   // wave 0: control
+    else lp_dual_simplex_role<NW, R, C, MP, DIVE, false, CUTS>(g, s);                   // tableau waves
 }
 
 #undef MIPX_PUBLISH_COL

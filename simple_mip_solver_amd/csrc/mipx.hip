@@ -72,7 +72,9 @@ struct KernelCfg {
 template <int NW, int R, int C, int MP>
 void launch_cfg(const mipx::LpArgs &a, int grid, hipStream_t st) {
     // the dive variant carries the pass loop (a few % slower per node LP): only when asked for
-    if (a.dive) hipLaunchKernelGGL((mipx::lp_dual_simplex<NW, R, C, MP, true>), dim3(grid), dim3(64 * (NW + 1)), 0, st, a);
+    // the cut-row variant reads its rows through the per-node cut lists: only when a launch has any
+    if (a.ncut) hipLaunchKernelGGL((mipx::lp_dual_simplex<NW, R, C, MP, false, true>), dim3(grid), dim3(64 * (NW + 1)), 0, st, a);
+    else if (a.dive) hipLaunchKernelGGL((mipx::lp_dual_simplex<NW, R, C, MP, true>), dim3(grid), dim3(64 * (NW + 1)), 0, st, a);
     else hipLaunchKernelGGL((mipx::lp_dual_simplex<NW, R, C, MP, false>), dim3(grid), dim3(64 * (NW + 1)), 0, st, a);
 }
 
@@ -98,10 +100,15 @@ bool big_fits(int m, int n) { return m >= 1 && m <= mipx::kBigMaxM && n <= mipx:
 bool shape_supported(int m, int n) { return pick_cfg(m, n) != nullptr || big_fits(m, n); }
 
 // Launch K1 (register-resident tableau) or, above its tiles, K1b (tableau streamed from HBM).
-int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t stream = nullptr) {
+// m_rows: the largest row count of any node of the launch when nodes carry cut rows (a.ncut), so
+// that the tile covers it (results do not depend on the tile); -1: the problem's own m.
+int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t stream = nullptr, int m_rows = -1) {
     mipx_ctx *ctx = p->ctx;
     if (!stream) stream = ctx->stream;
-    if (const KernelCfg *cfg = pick_cfg(p->m, p->n)) {
+    if (m_rows < 0) m_rows = p->m;
+    if (a.ncut && !pick_cfg(m_rows, p->n))
+        return fail(ctx, MIPX_ETOOBIG, "cut rows are only supported on the register-tile kernels");
+    if (const KernelCfg *cfg = pick_cfg(m_rows, p->n)) {
 #ifdef MIPX_KPROF
         // profiling build: per-section cycle totals of wave 0, summed over the launch
         static unsigned long long *d_prof = nullptr;
@@ -155,8 +162,8 @@ int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t strea
 
 }  // namespace
 
-#include "tree_engine.hip.h"
 #include "cut_kernels.hip.h"
+#include "tree_engine.hip.h"
 
 extern "C" {
 
@@ -321,6 +328,81 @@ int mipx_lp_solve_batch(mipx_problem *p, int batch, const double *l, const doubl
     if (npivots) HIP_TRY(ctx, hipMemcpyAsync(npivots, base + o_np, B * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return MIPX_OK;
+}
+
+int mipx_lp_solve_batch_cuts(mipx_problem *p, int batch, const double *l, const double *u,
+                             const int8_t *vstat_in, int ncuts_total, const double *cut_pi,
+                             const double *cut_pi0, int kc, const int32_t *ncut,
+                             const int32_t *cut_ids, int max_iter, int32_t *status, double *obj,
+                             double *x, double *y, int8_t *vstat_out, int32_t *iters,
+                             int32_t *npivots) {
+    if (!p) return MIPX_EINVAL;
+    mipx_ctx *ctx = p->ctx;
+    if (batch < 0 || kc < 1 || kc > 64 || ncuts_total < 0 || (ncuts_total && (!cut_pi || !cut_pi0)) ||
+        (batch > 0 && (!l || !u || !ncut || !cut_ids)))
+        return fail(ctx, MIPX_EINVAL, "mipx_lp_solve_batch_cuts: bad argument");
+    if (batch == 0) return MIPX_OK;
+    int maxc = 0;
+    for (int k = 0; k < batch; k++) {
+        if (ncut[k] < 0 || ncut[k] > kc) return fail(ctx, MIPX_EINVAL, "mipx_lp_solve_batch_cuts: ncut out of range");
+        for (int i = 0; i < ncut[k]; i++)
+            if (cut_ids[(size_t)k * kc + i] < 0 || cut_ids[(size_t)k * kc + i] >= ncuts_total)
+                return fail(ctx, MIPX_EINVAL, "mipx_lp_solve_batch_cuts: cut id out of range");
+        if (ncut[k] > maxc) maxc = ncut[k];
+    }
+    if (!pick_cfg(p->m + maxc, p->n)) return fail(ctx, MIPX_ETOOBIG, "mipx_lp_solve_batch_cuts: m + cuts exceeds the register tiles");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t B = (size_t)batch, n = (size_t)p->n, M = (size_t)p->m + kc, nvs = n + M, NC = (size_t)(ncuts_total ? ncuts_total : 1);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_l = carve(B * n * 8), o_u = carve(B * n * 8), o_vin = carve(B * nvs), o_cp = carve(NC * n * 8),
+                 o_c0 = carve(NC * 8), o_nc = carve(B * 4), o_id = carve(B * kc * 4), o_st = carve(B * 4),
+                 o_obj = carve(B * 8), o_x = carve(B * n * 8), o_y = carve(B * M * 8), o_vout = carve(B * nvs),
+                 o_it = carve(B * 4), o_np = carve(B * 4);
+    char *base = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&base, off));
+    hipStream_t st = ctx->stream;
+    auto run = [&]() -> int {
+        HIP_TRY(ctx, hipMemcpyAsync(base + o_l, l, B * n * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(base + o_u, u, B * n * 8, hipMemcpyHostToDevice, st));
+        if (vstat_in) HIP_TRY(ctx, hipMemcpyAsync(base + o_vin, vstat_in, B * nvs, hipMemcpyHostToDevice, st));
+        if (ncuts_total) {
+            HIP_TRY(ctx, hipMemcpyAsync(base + o_cp, cut_pi, (size_t)ncuts_total * n * 8, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(base + o_c0, cut_pi0, (size_t)ncuts_total * 8, hipMemcpyHostToDevice, st));
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(base + o_nc, ncut, B * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(base + o_id, cut_ids, B * kc * 4, hipMemcpyHostToDevice, st));
+        mipx::LpArgs a;
+        a.m = p->m; a.n = p->n;
+        a.A = p->dA; a.b = p->db; a.c = p->dc;
+        a.A_stride = a.b_stride = a.c_stride = 0;
+        a.l = (const double *)(base + o_l); a.u = (const double *)(base + o_u);
+        a.vstat_in = vstat_in ? (const int8_t *)(base + o_vin) : nullptr;
+        a.slot = nullptr; a.max_iter = max_iter;
+        a.anchor_T = nullptr; a.anchor_vec = nullptr; a.anchor_idx = nullptr; a.refactor_only = 0;
+        a.status = (int32_t *)(base + o_st); a.obj = (double *)(base + o_obj); a.x = (double *)(base + o_x);
+        a.y = (double *)(base + o_y); a.vstat_out = (int8_t *)(base + o_vout);
+        a.iters = (int32_t *)(base + o_it); a.npivots = (int32_t *)(base + o_np); a.batch = batch;
+        a.dbg_T = nullptr; a.dbg_vec = nullptr; a.dbg_idx = nullptr; a.dbg_all = 0;
+        a.ncut = (const int32_t *)(base + o_nc); a.cut_ids = (const int32_t *)(base + o_id);
+        a.cut_pi = (const double *)(base + o_cp); a.cut_pi0 = (const double *)(base + o_c0);
+        a.cut_stride = kc; a.mstride = (int)M; a.vstat_by_node = 0; a.active = nullptr;
+        const int rc = launch_lp_any(p, a, batch, nullptr, p->m + maxc);
+        if (rc) return rc;
+        if (status) HIP_TRY(ctx, hipMemcpyAsync(status, base + o_st, B * 4, hipMemcpyDeviceToHost, st));
+        if (obj) HIP_TRY(ctx, hipMemcpyAsync(obj, base + o_obj, B * 8, hipMemcpyDeviceToHost, st));
+        if (x) HIP_TRY(ctx, hipMemcpyAsync(x, base + o_x, B * n * 8, hipMemcpyDeviceToHost, st));
+        if (y) HIP_TRY(ctx, hipMemcpyAsync(y, base + o_y, B * M * 8, hipMemcpyDeviceToHost, st));
+        if (vstat_out) HIP_TRY(ctx, hipMemcpyAsync(vstat_out, base + o_vout, B * nvs, hipMemcpyDeviceToHost, st));
+        if (iters) HIP_TRY(ctx, hipMemcpyAsync(iters, base + o_it, B * 4, hipMemcpyDeviceToHost, st));
+        if (npivots) HIP_TRY(ctx, hipMemcpyAsync(npivots, base + o_np, B * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        return MIPX_OK;
+    };
+    const int rc = run();
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(base);
+    return rc;
 }
 
 int mipx_lp_dive_batch(mipx_problem *p, int batch, const double *l, const double *u,

@@ -27,6 +27,7 @@ struct NodeRec {
     int32_t b_dir;       // 0 left (x <= floor), 1 right (x >= ceil)
     int32_t anchor;      // entry of the anchor table its warm start refactors from (-1: the root's)
     int32_t born;        // step that created the node (MIPX_TREE_PROFILE: age histogram)
+    int32_t ncut;        // cut rows the node carries (cut rounds: inherited from its parent)
     // (no default initialisers: a fresh block of the node table must not be touched page by page)
 };
 
@@ -202,6 +203,14 @@ struct StepBuf {
     std::vector<NodeRec> recs;  // the batch's node records, copied at pop time (one random access per node and step)
     std::vector<int32_t> slots, br_pos, br_slot, br_var, br_child;  // staging kept alive
     std::vector<int32_t> br2_pos, br2_slot, br2_var, br2_child, dive_slots;  // children of the dive children
+    // cut rounds (mipx_tree_create_ex with cut parameters): per node of the batch the working cut
+    // list, the row duals, the loop's state and the pool of candidate cuts (a slab of slab_rows rows)
+    int32_t *w_ncut = nullptr, *w_ids = nullptr, *cs_state = nullptr, *cs_active = nullptr,
+            *cs_resolve = nullptr, *cs_counters = nullptr, *k2_ncuts = nullptr, *k3_nadded = nullptr,
+            *k3_added = nullptr, *k3_term = nullptr, *pool_list = nullptr, *dump_idx = nullptr;
+    double *d_y = nullptr, *cs_before = nullptr, *slab_pi = nullptr, *slab_pi0 = nullptr,
+           *dump_T = nullptr, *dump_vec = nullptr;
+    int32_t *h_cs = nullptr;   // pinned: [counters (4) | state fields 0..6 + w_ncut (8 x max_batch)]
     bool dive = false;  // this step was launched with the in-place dive
     bool scored_once = false;  // K4 ran on this step (the first run's request counter was zeroed by K1)
     int B = 0;
@@ -261,7 +270,7 @@ struct mipx_tree {
     std::vector<double> best_x;
     bool have_x = false, unbounded = false, started = false;
     int status = 0;  // 0 unsolved, 1 optimal, 2 infeasible, 3 unbounded, 4 stopped
-    int64_t evaluated = 0, lps = 0, probes = 0, pivots = 0, steps = 0;
+    int64_t evaluated = 0, lps = 0, probes = 0, pivots = 0, steps = 0, cut_resolves = 0;
     double solve_seconds = 0.0, kernel_ms = 0.0;
     std::vector<double> cost_l, cost_r;
     std::vector<int32_t> times_l, times_r;
@@ -272,6 +281,19 @@ struct mipx_tree {
     std::vector<double> tr_obj;
     bool trace = false;
     bool anchor_mode = false, anchor_set = false;
+    // cut rounds
+    bool cuts = false;
+    mipx_cut_params cp{};
+    int kc = 0;             // cut rows a node can carry
+    int mrows = 0;          // rows allotted per node: m + kc (m without cut rounds)
+    int slab_rows = 0;      // candidate cuts a node can hold while it is being bounded
+    double *store_pi = nullptr, *store_pi0 = nullptr;   // the cut store (append-only)
+    int32_t *store_count = nullptr;
+    int64_t store_cap = 0;
+    int32_t *pool_ncut = nullptr, *pool_ids = nullptr;  // node pool: the nodes' cut lists
+    int32_t *pp_ncut = nullptr, *pp_ids = nullptr;      // probe pool
+    uint8_t *d_is_int = nullptr;
+    int64_t cut_totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rounds, it/n created, it/n added, it/n removed, dropped
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // MIPX_TREE_PROFILE=1: host-side breakdown
     double probe_ms[4] = {0, 0, 0, 0};  // probes phase: requests | enqueue | wait | results
 };
@@ -328,10 +350,22 @@ void tree_push(mipx_tree *t, int64_t id) {
     }
 }
 
+// what a launch over nodes with cut rows adds to launch_lp (cut rounds only)
+struct CutLaunch {
+    const int32_t *ncut = nullptr, *ids = nullptr;   // the nodes' cut lists, by batch position
+    int vstat_by_node = 0;                           // the warm-start bases are dense too (l, u through slot)
+    const int32_t *active = nullptr;                 // skip mask
+    double *y = nullptr;                             // row duals out (batch x mrows)
+    int m_rows = -1;                                 // largest row count in the launch (tile choice)
+    double *dT = nullptr, *dvec = nullptr;           // dump every node's final tableau (K2's input)
+    int32_t *didx = nullptr;
+    bool no_anchor = false;
+};
+
 int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const int8_t *v,
               const int32_t *slot, int max_iter, int32_t *status, double *obj, double *x,
               int8_t *vout, int32_t *iters, int32_t *npiv, hipStream_t stream = nullptr,
-              const StepBuf *dive = nullptr, const int32_t *asel = nullptr) {
+              const StepBuf *dive = nullptr, const int32_t *asel = nullptr, const CutLaunch *cl = nullptr) {
     mipx::LpArgs a;
     if (dive) {  // in-place dive: K4's rule inside K1, children at positions batch .. 2 * batch - 1
         a.dive = 1; a.dive_off = batch; a.rule = t->rule; a.n_int = t->n_int;
@@ -355,7 +389,17 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
     a.status = status; a.obj = obj; a.x = x; a.y = nullptr; a.vstat_out = vout;
     a.iters = iters; a.npivots = npiv; a.batch = batch;
     a.dbg_T = nullptr; a.dbg_vec = nullptr; a.dbg_idx = nullptr; a.dbg_all = 0;
-    return launch_lp_any(t->prob, a, batch, stream);
+    int m_rows = -1;
+    if (cl != nullptr) {
+        a.ncut = cl->ncut; a.cut_ids = cl->ids; a.cut_stride = t->kc;
+        a.cut_pi = t->store_pi; a.cut_pi0 = t->store_pi0;
+        a.mstride = t->mrows; a.vstat_by_node = cl->vstat_by_node; a.active = cl->active;
+        a.y = cl->y;
+        if (cl->dT) { a.dbg_T = cl->dT; a.dbg_vec = cl->dvec; a.dbg_idx = cl->didx; a.dbg_all = 1; }
+        if (cl->no_anchor) { a.anchor_T = nullptr; a.anchor_vec = nullptr; a.anchor_idx = nullptr; }
+        m_rows = cl->m_rows;
+    }
+    return launch_lp_any(t->prob, a, batch, stream, m_rows);
 }
 
 // Device -> host copies of the step loop go through the side stream, never the null stream: a
@@ -370,7 +414,7 @@ int tree_d2h(mipx_tree *t, void *dst, const void *src, size_t bytes) {
 
 constexpr int kAskCap = 2048;  // probe requests per step carried in the packed read-back
 
-int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false) {
+int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false, bool no_ask = false) {
     mipx::ScoreArgs s;
     s.n = t->n; s.n_int = t->n_int; s.batch = batch; s.rule = t->rule;
     s.int_idx = t->d_int_idx; s.x = S.d_x; s.status = S.d_status;
@@ -379,11 +423,11 @@ int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false) {
     s.branch_idx = S.d_bidx; s.branch_val = S.d_bval; s.mip_feasible = S.d_mipf;
     s.n_probe = S.d_nprobe;
     s.probe_list = S.d_plist;
-    s.ask_count = S.d_ask_count; s.ask_cap = kAskCap; s.ask = side ? nullptr : S.d_ask;
+    s.ask_count = S.d_ask_count; s.ask_cap = kAskCap; s.ask = (side || no_ask) ? nullptr : S.d_ask;
     s.ask_nodes = S.B;  // dive children (positions >= B) are never probed in their own step
-    if (!side && !(S.dive && batch == 2 * S.B && !S.scored_once))
+    if (!side && !no_ask && !(S.dive && batch == 2 * S.B && !S.scored_once))
         HIP_TRY(t->ctx, hipMemsetAsync(S.d_ask_count, 0, 16, t->ctx->stream));
-    S.scored_once = true;
+    if (!no_ask) S.scored_once = true;
     hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, side ? t->st2 : t->ctx->stream, s);
     HIP_TRY(t->ctx, hipGetLastError());
     return MIPX_OK;
@@ -471,13 +515,157 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
     }
     S.dive = t->dive;  // (register tiles and the HBM-streaming kernel alike)
     S.scored_once = false;
+    int rc = MIPX_OK;
+    if (t->cuts) {
+        // working copies of the nodes' cut lists, the loop state zeroed; then the node LPs over their
+        // m + ncut rows (row duals kept: the slack-cut removal reads them) and the integrality test
+        HIP_TRY(ctx, hipMemsetAsync(S.cs_counters, 0, 16, st));
+        mipx::CutGatherArgs ga;
+        ga.batch = B; ga.kc = t->kc; ga.slot = S.d_slot;
+        ga.pool_ncut = t->pool_ncut; ga.pool_ids = t->pool_ids;
+        ga.ncut = S.w_ncut; ga.ids = S.w_ids; ga.state = S.cs_state; ga.counters = S.cs_counters;
+        hipLaunchKernelGGL(mipx::cut_gather_state, dim3(B), dim3(64), 0, st, ga);
+        HIP_TRY(ctx, hipGetLastError());
+        int maxc = 0;
+        for (int k = 0; k < B; k++) maxc = std::max(maxc, (int)S.recs[(size_t)k].ncut);
+        CutLaunch cl;
+        cl.ncut = S.w_ncut; cl.ids = S.w_ids; cl.y = S.d_y; cl.m_rows = t->m + maxc;
+        HIP_TRY(ctx, hipEventRecord(S.e0, st));
+        rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, S.d_slot, 0, S.d_status, S.d_obj, S.d_x,
+                       S.d_vout, S.d_iters, S.d_npiv, nullptr, nullptr, nullptr, &cl);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipEventRecord(S.e1, st));
+        if ((rc = launch_score(t, S, B, false, true))) return rc;
+        HIP_TRY(ctx, hipEventRecord(S.done, st));
+        return MIPX_OK;
+    }
     HIP_TRY(ctx, hipEventRecord(S.e0, st));
-    int rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, S.d_slot, 0, S.d_status, S.d_obj,
-                       S.d_x, S.d_vout, S.d_iters, S.d_npiv, nullptr, S.dive ? &S : nullptr, S.d_slot + B);
+    rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, S.d_slot, 0, S.d_status, S.d_obj,
+                   S.d_x, S.d_vout, S.d_iters, S.d_npiv, nullptr, S.dive ? &S : nullptr, S.d_slot + B);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(S.e1, st));
     if ((rc = launch_score(t, S, S.dive ? 2 * B : B))) return rc;
     HIP_TRY(ctx, hipEventRecord(S.done, st));
+    return MIPX_OK;
+}
+
+// The cut loop of BaseNode._base_bound (base_node.py:196-203) for the whole batch at once: round r
+// of every node that is still generating runs together.  Per round two small read-backs (how many
+// nodes go on; how many LPs changed and the largest row count), everything else stays on the device:
+//   cut_round_begin   stall test of the last round, loop condition, slack-cut removal   (:292-341)
+//   K1                the tableau of the basis on the remaining rows                     (:513-526)
+//   K2 + pool_append  GMI cuts, safely rounded, into the node's pool                     (:365-385, :468-511)
+//   K3                selection                                                          (:387-454)
+//   cut_round_apply   selected cuts -> cut store, node list, basis; pool minus selected  (:456-463)
+//   K1 + K4           re-solve of the nodes whose rows changed, integrality test         (:319)
+// A node whose rows did not change is not re-solved (the reference re-solves the unchanged LP and
+// gets the same objective: it stalls either way).
+int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
+    mipx_ctx *ctx = t->ctx;
+    hipStream_t st = ctx->stream;
+    const int B = S.B, n = t->n;
+    const size_t MB = (size_t)t->max_batch;
+    int maxc = 0;
+    for (int k = 0; k < B; k++) maxc = std::max(maxc, (int)S.recs[(size_t)k].ncut);
+    for (int round = 0;; round++) {
+        HIP_TRY(ctx, hipMemsetAsync(S.cs_counters, 0, 8, st));   // n_active, n_changed (max_ncut stays)
+        mipx::CutRoundArgs ra;
+        ra.n = n; ra.m0 = t->m; ra.mstride = t->mrows; ra.kc = t->kc; ra.batch = B; ra.round = round;
+        ra.max_rounds = t->cp.max_cut_generation_iterations;
+        ra.progress_tol = t->cp.cutting_plane_progress_tolerance; ra.max_dual_bound = t->cp.max_dual_bound;
+        ra.status = S.d_status; ra.obj = S.d_obj; ra.mipf = S.d_mipf; ra.y = S.d_y; ra.vstat = S.d_vout;
+        ra.ncut = S.w_ncut; ra.ids = S.w_ids; ra.state = S.cs_state; ra.obj_before = S.cs_before;
+        ra.active = S.cs_active; ra.resolve = S.cs_resolve; ra.counters = S.cs_counters;
+        hipLaunchKernelGGL(mipx::cut_round_begin, dim3(B), dim3(64), 0, st, ra);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(S.h_cs, S.cs_counters, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (S.h_cs[0] == 0) break;   // nobody generates any more
+        // the tableau of every generating node's basis (refactorisation from the slack basis -- or,
+        // without exact_tableau, from the root's anchor where the node has no cut rows -- then zero
+        // iterations: the basis is optimal), dumped for K2
+        CutLaunch cl;
+        cl.ncut = S.w_ncut; cl.ids = S.w_ids; cl.vstat_by_node = 1; cl.active = S.cs_active;
+        cl.m_rows = t->m + maxc; cl.dT = S.dump_T; cl.dvec = S.dump_vec; cl.didx = S.dump_idx;
+        cl.no_anchor = t->cp.exact_tableau != 0;
+        int rc = launch_lp(t, B, t->pool_l, t->pool_u, S.d_vout, S.d_slot, 0, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &cl);
+        if (rc) return rc;
+        mipx::GomoryArgs ga;
+        ga.m = t->m; ga.n = n; ga.batch = B;
+        ga.A = t->prob->dA; ga.b = t->prob->db;
+        ga.T = S.dump_T; ga.idx = S.dump_idx; ga.x = S.d_x; ga.is_int = t->d_is_int;
+        ga.max_term = t->cp.max_term;
+        ga.ncuts = S.k2_ncuts; ga.row_idx = nullptr; ga.pi = nullptr; ga.pi0 = nullptr;
+        ga.safe_pi = nullptr; ga.safe_pi0 = nullptr;
+        ga.chunks = B >= 256 ? 1 : (B >= 32 ? 4 : 16);
+        ga.ncut = S.w_ncut; ga.cut_ids = S.w_ids; ga.cut_pi = t->store_pi; ga.cut_pi0 = t->store_pi0;
+        ga.cut_stride = t->kc; ga.mstride = t->mrows; ga.vstat = S.d_vout; ga.clip_x = 1;
+        ga.active = S.cs_active;
+        ga.slab_pi = S.slab_pi; ga.slab_pi0 = S.slab_pi0;
+        ga.slab_n = S.cs_state + (size_t)mipx::CF_SLAB_N * B; ga.slab_rows = t->slab_rows;
+        const size_t lds2 = ((size_t)n + t->mrows + 64) * 8 + (2 * (size_t)t->mrows + n) * 4 + 64;
+        hipLaunchKernelGGL((mipx::gomory_cuts<256>), dim3(B * ga.chunks), dim3(256), lds2, st, ga);
+        HIP_TRY(ctx, hipGetLastError());
+        mipx::PoolAppendArgs pa;
+        pa.batch = B; pa.slab_rows = t->slab_rows; pa.active = S.cs_active; pa.k2_ncuts = S.k2_ncuts;
+        pa.state = S.cs_state; pa.pool_list = S.pool_list;
+        hipLaunchKernelGGL(mipx::pool_append, dim3((B + 63) / 64), dim3(64), 0, st, pa);
+        HIP_TRY(ctx, hipGetLastError());
+        mipx::SelectArgs sa;
+        sa.n = n; sa.batch = B; sa.kmax = t->slab_rows;
+        sa.npool = S.cs_state + (size_t)mipx::CF_POOL_N * B; sa.pi = S.slab_pi; sa.pi0 = S.slab_pi0; sa.x = S.d_x;
+        sa.max_nonzero_coefs = t->cp.max_nonzero_coefs; sa.min_cut_depth = t->cp.min_cut_depth;
+        sa.cos_parallel = t->cp.cos_parallel; sa.max_abs_coef = t->cp.max_abs_coef;
+        sa.nadded = S.k3_nadded; sa.added = S.k3_added; sa.terminator = S.k3_term; sa.depth = nullptr;
+        sa.pool_list = S.pool_list; sa.clip_x = 1; sa.active = S.cs_active;
+        const size_t lds3 = (size_t)t->slab_rows * (3 * 8 + 2 * 4) + 16 + 64;
+        hipLaunchKernelGGL(mipx::select_cuts, dim3(B), dim3(256), lds3, st, sa);
+        HIP_TRY(ctx, hipGetLastError());
+        mipx::CutApplyArgs aa;
+        aa.n = n; aa.m0 = t->m; aa.mstride = t->mrows; aa.kc = t->kc; aa.batch = B; aa.slab_rows = t->slab_rows;
+        aa.active = S.cs_active; aa.k3_nadded = S.k3_nadded; aa.k3_added = S.k3_added;
+        aa.slab_pi = S.slab_pi; aa.slab_pi0 = S.slab_pi0; aa.pool_list = S.pool_list;
+        aa.vstat = S.d_vout; aa.ncut = S.w_ncut; aa.ids = S.w_ids; aa.state = S.cs_state;
+        aa.store_pi = t->store_pi; aa.store_pi0 = t->store_pi0; aa.store_count = t->store_count;
+        aa.store_cap = (int)t->store_cap;
+        aa.resolve = S.cs_resolve; aa.counters = S.cs_counters;
+        hipLaunchKernelGGL(mipx::cut_round_apply, dim3(B), dim3(256), 0, st, aa);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(S.h_cs, S.cs_counters, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        const int changed = S.h_cs[1];
+        maxc = std::max(maxc, (int)S.h_cs[2]);
+        if (changed > 0) {   // re-solve where rows came or went, warm from the node's own basis (:319)
+            CutLaunch rl;
+            rl.ncut = S.w_ncut; rl.ids = S.w_ids; rl.vstat_by_node = 1; rl.active = S.cs_resolve;
+            rl.y = S.d_y; rl.m_rows = t->m + maxc;
+            rl.no_anchor = true;   // (a node that changed rows has, or just had, cut rows)
+            rc = launch_lp(t, B, t->pool_l, t->pool_u, S.d_vout, S.d_slot, 0, S.d_status, S.d_obj, S.d_x,
+                           S.d_vout, S.d_iters, S.d_npiv, nullptr, nullptr, nullptr, &rl);
+            if (rc) return rc;
+            if ((rc = launch_score(t, S, B, false, true))) return rc;
+            t->lps += changed;
+            t->cut_resolves += changed;
+        }
+    }
+    // per node: rounds and the six GMIC counters, its final number of cut rows
+    HIP_TRY(ctx, hipMemcpyAsync(S.h_cs + 4, S.cs_state, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    for (int f = 1; f < 7; f++)
+        HIP_TRY(ctx, hipMemcpyAsync(S.h_cs + 4 + (size_t)f * MB, S.cs_state + (size_t)f * B, (size_t)B * 4,
+                                    hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(S.h_cs + 4 + 7 * MB, S.w_ncut, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(S.h_cs + 4 + 8 * MB, S.cs_state + (size_t)mipx::CF_DROPPED * B, (size_t)B * 4,
+                                hipMemcpyDeviceToHost, st));
+    // the final scoring of the batch (branching variable, strong-branching requests)
+    int rc = launch_score(t, S, B);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(S.done, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int k = 0; k < B; k++) {
+        for (int f = 0; f < 7; f++) t->cut_totals[f] += S.h_cs[4 + (size_t)f * MB + k];
+        t->cut_totals[7] += S.h_cs[4 + 8 * MB + k];
+    }
     return MIPX_OK;
 }
 
@@ -498,6 +686,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     const std::vector<int64_t> &ids = S.ids;
     const std::vector<int32_t> &slots = S.slots;
     int rc = MIPX_OK;
+    if (t->cuts && (rc = tree_cut_rounds(t, S))) return rc;
     HIP_TRY(ctx, hipEventSynchronize(S.done));
     {
         float ms = 0.f;
@@ -583,11 +772,20 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             ca.x = S.d_x; ca.vstat = S.d_vout;
             ca.dst_l = t->pp_l; ca.dst_u = t->pp_u; ca.dst_v = t->pp_v;
             ca.child_slot = dp + 3 * P;
+            CutLaunch pcl;
+            if (t->cuts) {  // a probe is a child: it has its parent's rows, cuts included (base_node.py:602-606)
+                ca.mstride = t->mrows; ca.kc = t->kc;
+                ca.src_ncut = S.w_ncut; ca.src_ids = S.w_ids; ca.dst_ncut = t->pp_ncut; ca.dst_ids = t->pp_ids;
+                int maxc = 0;
+                for (int k = 0; k < B; k++) maxc = std::max(maxc, (int)S.h_cs[4 + 7 * MB + k]);
+                pcl.ncut = t->pp_ncut; pcl.ids = t->pp_ids; pcl.m_rows = t->m + maxc;
+            }
             hipLaunchKernelGGL(mipx::make_children, dim3(2 * P), dim3(256), 0, ps, ca);
             HIP_TRY(ctx, hipGetLastError());
             // truncated dual simplex on every probe (base_node.py:645-646)
             rc = launch_lp(t, 2 * P, t->pp_l, t->pp_u, t->pp_v, nullptr, t->sb_iters, t->pp_status,
-                           t->pp_obj, nullptr, nullptr, nullptr, nullptr, ps);
+                           t->pp_obj, nullptr, nullptr, nullptr, nullptr, ps, nullptr, nullptr,
+                           t->cuts ? &pcl : nullptr);
             if (rc) return rc;
             pst.resize(2 * (size_t)P);
             pobj.resize(2 * (size_t)P);
@@ -698,6 +896,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
                     c.b_idx = branched_on; c.b_dir = dir; c.b_val = xv;
                     c.born = (int32_t)t->steps;
                     c.anchor = anchor;
+                    c.ncut = t->cuts ? S.h_cs[4 + 7 * MB + pos] : 0;   // the rows of its parent, cuts included
                     c.slot = t->free_slots.back();
                     t->free_slots.pop_back();
                     (level == 0 ? br_child : br2_child).push_back(c.slot);
@@ -744,7 +943,9 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     }
     t->phase_ms[3] += ms_since(tp); tp = now();
     // anchor mode: the refactorisations of every later node start from the root's optimal tableau
-    if (t->anchor_mode && !t->anchor_set && ids[0] == 0 && status[0] == 0) {
+    // (cut rounds: only a root that kept no cut rows has a basis of the shared rows alone)
+    if (t->anchor_mode && !t->anchor_set && ids[0] == 0 && status[0] == 0 &&
+        !(t->cuts && S.h_cs[4 + 7 * MB] != 0)) {
         std::vector<int8_t> rootv(nv);
         HIP_TRY(ctx, hipMemcpy(rootv.data(), S.d_vout, (size_t)nv, hipMemcpyDeviceToHost));
         const int arc = mipx_problem_set_anchor(t->prob, rootv.data());
@@ -773,6 +974,10 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             ca.x = S.d_x; ca.vstat = S.d_vout;
             ca.dst_l = t->pool_l; ca.dst_u = t->pool_u; ca.dst_v = t->pool_v;
             ca.child_slot = dp + 3 * cnt;
+            if (t->cuts) {
+                ca.mstride = t->mrows; ca.kc = t->kc;
+                ca.src_ncut = S.w_ncut; ca.src_ids = S.w_ids; ca.dst_ncut = t->pool_ncut; ca.dst_ids = t->pool_ids;
+            }
             hipLaunchKernelGGL(mipx::make_children, dim3(2 * cnt), dim3(256), 0, cs, ca);
             HIP_TRY(ctx, hipGetLastError());
             return MIPX_OK;
@@ -803,12 +1008,33 @@ extern "C" {
 int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const double *l,
                      const double *u, int branch_rule, int search_rule, int strong_branch_iters,
                      int max_batch, int64_t pool_capacity, mipx_tree **out) {
+    return mipx_tree_create_ex(p, int_idx, n_int, l, u, branch_rule, search_rule, strong_branch_iters,
+                               max_batch, pool_capacity, nullptr, out);
+}
+
+int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, const double *l,
+                        const double *u, int branch_rule, int search_rule, int strong_branch_iters,
+                        int max_batch, int64_t pool_capacity, const mipx_cut_params *cuts,
+                        mipx_tree **out) {
     if (!p || !out || n_int < 0 || (n_int && !int_idx) || !l || !u || max_batch < 1 ||
         branch_rule < 0 || branch_rule > 1 || search_rule < 0 || search_rule > 1 ||
         strong_branch_iters < 1)
         return fail(p ? p->ctx : nullptr, MIPX_EINVAL, "mipx_tree_create: bad argument");
     mipx_ctx *ctx = p->ctx;
     *out = nullptr;
+    int kc = 0;
+    if (cuts != nullptr) {
+        kc = cuts->max_cuts_per_node > 0 ? cuts->max_cuts_per_node : mipx::kMaxNodeCuts;
+        if (kc > mipx::kMaxNodeCuts || cuts->max_cut_generation_iterations < 1 || cuts->max_nonzero_coefs < 1 ||
+            !(cuts->cutting_plane_progress_tolerance > 0) || !(cuts->min_cut_depth > 0) || !(cuts->max_term > 0) ||
+            cuts->store_capacity < 0)
+            return fail(ctx, MIPX_EINVAL, "mipx_tree_create_ex: bad cut parameter");
+        // the rows of a node must fit a register tile; keep as many cut rows as the largest tile takes
+        while (kc > 0 && pick_cfg(p->m + kc, p->n) == nullptr) kc--;
+        if (kc == 0)
+            return fail(ctx, MIPX_ETOOBIG, "mipx_tree_create_ex: cut rounds need m + cuts <= 192 rows, n <= 256 "
+                                            "(the register-tile kernels)");
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     mipx_tree *t = new (std::nothrow) mipx_tree();
     if (!t) return fail(ctx, MIPX_ENOMEM, "mipx_tree_create: host alloc");
@@ -820,7 +1046,22 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     t->int_idx.assign(int_idx, int_idx + n_int);
     for (int i = 0; i < n_int; i++)
         if (int_idx[i] < 0 || int_idx[i] >= t->n) { delete t; return fail(ctx, MIPX_EINVAL, "mipx_tree_create: integer index out of range"); }
-    const size_t n = t->n, nv = t->n + t->m, cap = (size_t)t->capacity, B = (size_t)max_batch;
+    t->cuts = cuts != nullptr;
+    t->kc = kc;
+    t->mrows = t->m + kc;
+    if (t->cuts) {
+        t->cp = *cuts;
+        t->store_cap = cuts->store_capacity > 0 ? cuts->store_capacity : ((int64_t)1 << 20);
+        if (t->store_cap > 0x7fffffff) t->store_cap = 0x7fffffff;
+        // candidate cuts of one node while it is bounded: every round adds at most one per row; K3
+        // keeps three doubles and two ints per candidate in LDS (64 KiB)
+        int64_t rows = (int64_t)cuts->max_cut_generation_iterations * t->mrows;
+        if (rows > 2040) rows = 2040;
+        if (rows < t->mrows) rows = t->mrows;
+        t->slab_rows = (int)rows;
+        t->pipeline = false;   // (the cut loop of a step reads back per round: steps do not overlap)
+    }
+    const size_t n = t->n, nv = (size_t)t->n + t->mrows, cap = (size_t)t->capacity, B = (size_t)max_batch;
     t->probe_cap = 2 * (int64_t)B * (n_int ? n_int : 1);
     if (t->probe_cap > (int64_t)1 << 18) t->probe_cap = (int64_t)1 << 18;  // 2^18 probe records (~1.2 GB at 256x128)
     const size_t pc = (size_t)t->probe_cap;
@@ -842,6 +1083,28 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     if (hipStreamCreateWithPriority(&t->st3, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&t->ev_child, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&t->h_pairs, 10 * B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
+    if (t->cuts) {
+        const size_t M = (size_t)t->mrows, K = (size_t)t->kc, SR = (size_t)t->slab_rows;
+        rc |= dmalloc(ctx, &t->store_pi, (size_t)t->store_cap * n); rc |= dmalloc(ctx, &t->store_pi0, (size_t)t->store_cap);
+        rc |= dmalloc(ctx, &t->store_count, 4);
+        rc |= dmalloc(ctx, &t->pool_ncut, cap); rc |= dmalloc(ctx, &t->pool_ids, cap * K);
+        rc |= dmalloc(ctx, &t->pp_ncut, pc); rc |= dmalloc(ctx, &t->pp_ids, pc * K);
+        rc |= dmalloc(ctx, &t->d_is_int, n);
+        for (StepBuf &S : t->buf) {
+            rc |= dmalloc(ctx, &S.w_ncut, B); rc |= dmalloc(ctx, &S.w_ids, B * K);
+            rc |= dmalloc(ctx, &S.cs_state, (size_t)mipx::CF_FIELDS * B);
+            rc |= dmalloc(ctx, &S.cs_active, B); rc |= dmalloc(ctx, &S.cs_resolve, B);
+            rc |= dmalloc(ctx, &S.cs_counters, 4); rc |= dmalloc(ctx, &S.k2_ncuts, B);
+            rc |= dmalloc(ctx, &S.k3_nadded, B); rc |= dmalloc(ctx, &S.k3_added, B * SR);
+            rc |= dmalloc(ctx, &S.k3_term, B); rc |= dmalloc(ctx, &S.pool_list, B * SR);
+            rc |= dmalloc(ctx, &S.d_y, B * M); rc |= dmalloc(ctx, &S.cs_before, B);
+            rc |= dmalloc(ctx, &S.slab_pi, B * SR * n); rc |= dmalloc(ctx, &S.slab_pi0, B * SR);
+            rc |= dmalloc(ctx, &S.dump_T, B * M * n); rc |= dmalloc(ctx, &S.dump_vec, B * (n + 3 * M));
+            rc |= dmalloc(ctx, &S.dump_idx, B * (2 * n + M));
+            if (hipHostMalloc((void **)&S.h_cs, (4 + 9 * B) * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
+            if (!t->pipeline) break;   // steps do not overlap: one buffer set is in use
+        }
+    }
     for (StepBuf &S : t->buf) {
         rc |= dmalloc(ctx, &S.d_slot, 2 * B);   // [pool rows | anchor-table entries] of the batch
         // per-node outputs have 2 * B rows: the batch, then its dive children
@@ -892,12 +1155,20 @@ int mipx_tree_create(mipx_problem *p, const int32_t *int_idx, int n_int, const d
     HIP_TRY(ctx, hipMemcpy(t->pool_l, l, n * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(t->pool_u, u, n * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemset(t->pool_v, 0, nv));
+    if (t->cuts) {
+        std::vector<uint8_t> is_int(n, 0);
+        for (int i = 0; i < n_int; i++) is_int[(size_t)int_idx[i]] = 1;
+        HIP_TRY(ctx, hipMemcpy(t->d_is_int, is_int.data(), n, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemset(t->store_count, 0, 4));
+        HIP_TRY(ctx, hipMemset(t->pool_ncut, 0, 4));   // the root carries no cut
+    }
     t->free_slots.reserve(cap);
     for (int64_t s = (int64_t)cap - 1; s >= 1; s--) t->free_slots.push_back((int32_t)s);
     NodeRec root;
     root.dual_bound = -std::numeric_limits<double>::infinity();
     root.depth = 0; root.key = search_rule == 0 ? root.dual_bound : 0.0;
     root.b_idx = -1; root.b_dir = 0; root.b_val = 0.0; root.slot = 0; root.born = 0; root.anchor = -1;
+    root.ncut = 0;
     t->nodes.push_back(root);
     *out = t;
     return MIPX_OK;
@@ -917,6 +1188,17 @@ void mipx_tree_destroy(mipx_tree *t) {
     if (t->h_pairs) (void)hipHostFree(t->h_pairs);
     if (t->h_pres) (void)hipHostFree(t->h_pres);
     if (t->h_tab) (void)hipHostFree(t->h_tab);
+    void *cptrs[] = {t->store_pi, t->store_pi0, t->store_count, t->pool_ncut, t->pool_ids, t->pp_ncut, t->pp_ids, t->d_is_int};
+    for (void *q : cptrs)
+        if (q) (void)hipFree(q);
+    for (StepBuf &S : t->buf) {
+        void *sp[] = {S.w_ncut, S.w_ids, S.cs_state, S.cs_active, S.cs_resolve, S.cs_counters, S.k2_ncuts, S.k3_nadded,
+                      S.k3_added, S.k3_term, S.pool_list, S.d_y, S.cs_before, S.slab_pi, S.slab_pi0, S.dump_T, S.dump_vec,
+                      S.dump_idx};
+        for (void *q : sp)
+            if (q) (void)hipFree(q);
+        if (S.h_cs) (void)hipHostFree(S.h_cs);
+    }
     void *ptrs[] = {t->atab_T, t->atab_vec, t->atab_idx, t->pool_l, t->pool_u, t->pool_v, t->d_int_idx, t->d_pairs, t->d_pairs2, t->d_cost_l,
                     t->d_cost_l2, t->d_cost_r2, t->d_has2, t->pp_l, t->pp_u, t->pp_v, t->pp_obj, t->pp_status};
     for (void *q : ptrs)
@@ -1012,7 +1294,8 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
         if (t->buf[cur].in_flight) steps++;
     }
     while (t->buf[cur].in_flight) {
-        StepBuf &S = t->buf[cur], &N = t->buf[1 - cur];
+        // (steps that do not overlap run out of one buffer set: the cut loop's are large)
+        StepBuf &S = t->buf[cur], &N = overlap ? t->buf[1 - cur] : t->buf[cur];
         if (overlap && !tree_queue_empty(t) && !stop_now(S.B)) {
             const int want = batch_size(S.B);
             if (want > 0) {
@@ -1032,7 +1315,7 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
             if (rc) return rc;
             if (N.in_flight) steps++;
         }
-        cur = 1 - cur;
+        if (overlap) cur = 1 - cur;
     }
     HIP_TRY(ctx, hipStreamSynchronize(t->st3));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1069,6 +1352,7 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
 int mipx_tree_reanchor(mipx_tree *t, int64_t max_nodes) {
     if (!t || max_nodes < 1) return MIPX_EINVAL;
     mipx_ctx *ctx = t->ctx;
+    if (t->cuts) return fail(ctx, MIPX_EINVAL, "mipx_tree_reanchor: not available with cut rounds");
     if (!t->anchor_mode || !t->anchor_set)
         return fail(ctx, MIPX_EINVAL, "mipx_tree_reanchor: needs the anchor mode and a solved root");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1124,6 +1408,9 @@ int mipx_tree_set_dive(mipx_tree *t, int on) {
     if (on && t->max_batch == 1)
         return fail(t->ctx, MIPX_EINVAL, "mipx_tree_set_dive: the exact mode (max_batch = 1) reproduces the "
                                          "reference's node order and cannot dive");
+    if (on && t->cuts)
+        return fail(t->ctx, MIPX_EINVAL, "mipx_tree_set_dive: a dive child would be solved before its parent's cut "
+                                         "rounds; not available with cut rounds");
     t->dive = on != 0;
     return MIPX_OK;
 }
@@ -1155,6 +1442,12 @@ int mipx_tree_get_stats(mipx_tree *t, mipx_tree_stats *out) {
     out->dives = t->dives;
     out->pool_exhausted = t->pool_exhausted ? 1 : 0;
     out->reserved = 0;
+    return MIPX_OK;
+}
+
+int mipx_tree_cut_stats(mipx_tree *t, int64_t out[8]) {
+    if (!t || !out) return MIPX_EINVAL;
+    for (int k = 0; k < 8; k++) out[k] = t->cut_totals[k];
     return MIPX_OK;
 }
 
@@ -1195,7 +1488,7 @@ int64_t mipx_tree_peek_open(mipx_tree *t, int64_t max_nodes, double *l, double *
                             double *dual_bound) {
     if (!t || max_nodes < 0) return MIPX_EINVAL;
     mipx_ctx *ctx = t->ctx;
-    const size_t n = t->n, nv = t->n + t->m;
+    const size_t n = t->n, nv = t->n + t->m, nvs = (size_t)t->n + t->mrows;   // (cut rows of the basis are not copied)
     int64_t k = 0;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return MIPX_EHIP;
     std::vector<int64_t> order;
@@ -1205,7 +1498,7 @@ int64_t mipx_tree_peek_open(mipx_tree *t, int64_t max_nodes, double *l, double *
         const size_t s = (size_t)nd.slot;
         if (l && hipMemcpy(l + k * n, t->pool_l + s * n, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
         if (u && hipMemcpy(u + k * n, t->pool_u + s * n, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
-        if (vstat && hipMemcpy(vstat + k * nv, t->pool_v + s * nv, nv, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
+        if (vstat && hipMemcpy(vstat + k * nv, t->pool_v + s * nvs, nv, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
         if (dual_bound) dual_bound[k] = nd.dual_bound;
     }
     return k;

@@ -122,14 +122,22 @@ struct ChildArgs {
     double *dst_l, *dst_u;         // destination pool
     int8_t *dst_v;
     const int32_t *child_slot;     // 2*count: left (x <= floor) then right (x >= ceil)
+    // cut rounds (optional): rows allotted per node in vstat / dst_v (0: m), and the parent's cut list
+    // (dense, by parent_pos) copied to the child (by child_slot): base_node.py:602-606 copies every row
+    int mstride = 0, kc = 0;
+    const int32_t *src_ncut = nullptr, *src_ids = nullptr;
+    int32_t *dst_ncut = nullptr, *dst_ids = nullptr;
 };
 
 __global__ __launch_bounds__(256) void make_children(ChildArgs g) {
     const int c = blockIdx.x;  // child number: pair = c / 2, direction = c % 2
     if (c >= 2 * g.count) return;
     const int pair = c >> 1, right = c & 1;
-    const int n = g.n, nv = g.n + g.m;
+    const int n = g.n;
     const size_t ps = (size_t)g.parent_slot[pair], pos = (size_t)g.parent_pos[pair];
+    const int kcut = g.src_ncut ? g.src_ncut[pos] : 0;
+    const int nv = g.n + g.m + kcut;                             // entries of the parent's basis
+    const size_t vs = (size_t)(g.n + (g.mstride ? g.mstride : g.m));  // entries allotted per node
     const size_t ds = (size_t)g.child_slot[c];
     const int j = g.var[pair];
     const double xv = g.x[pos * n + j];
@@ -142,7 +150,202 @@ __global__ __launch_bounds__(256) void make_children(ChildArgs g) {
         g.dst_l[ds * n + k] = lo;
         g.dst_u[ds * n + k] = up;
     }
-    for (int k = threadIdx.x; k < nv; k += blockDim.x) g.dst_v[ds * nv + k] = g.vstat[pos * nv + k];
+    for (int k = threadIdx.x; k < nv; k += blockDim.x) g.dst_v[ds * vs + k] = g.vstat[pos * vs + k];
+    if (g.src_ncut != nullptr) {
+        for (int k = threadIdx.x; k < kcut; k += blockDim.x) g.dst_ids[ds * g.kc + k] = g.src_ids[pos * g.kc + k];
+        if (threadIdx.x == 0) g.dst_ncut[ds] = kcut;
+    }
+}
+
+// ---- cut rounds inside the frontier engine (reference base_node.py:137-230, :292-341) ------------
+// Per node of the batch a working copy of its cut list (ids into the engine's cut store, at most 64)
+// and a few counters; the kernels below are the host-free parts of _base_bound's loop: who is still
+// generating, the slack-cut removal, joining new cuts to the pool, applying K3's selection.
+// State arrays are int32[batch] each, laid out field-major in one allocation.
+enum CutField { CF_ROUNDS = 0, CF_IT_CREATED, CF_N_CREATED, CF_IT_ADDED, CF_N_ADDED, CF_IT_REMOVED,
+                CF_N_REMOVED, CF_NCUT_OUT, CF_STALLED, CF_POOL_N, CF_SLAB_N, CF_DROPPED, CF_FIELDS };
+constexpr int kMaxNodeCuts = 64;   // cut rows a node can carry (one wave handles a node's list)
+
+struct CutGatherArgs {
+    int batch, kc;
+    const int32_t *slot;                     // pool row of each node of the batch
+    const int32_t *pool_ncut, *pool_ids;     // node pool
+    int32_t *ncut, *ids;                     // working lists (dense)
+    int32_t *state;                          // CF_FIELDS x batch, zeroed here
+    int32_t *counters;                       // [n_active, n_changed, max_ncut, -]: max_ncut initialised here
+};
+__global__ __launch_bounds__(64) void cut_gather_state(CutGatherArgs g) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (k >= g.batch) return;
+    const size_t s = (size_t)g.slot[k];
+    const int nc = g.pool_ncut[s];
+    if (lane < nc) g.ids[(size_t)k * g.kc + lane] = g.pool_ids[s * g.kc + lane];
+    if (lane == 0) {
+        g.ncut[k] = nc;
+        atomicMax(&g.counters[2], nc);
+    }
+    if (lane < CF_FIELDS) g.state[(size_t)lane * g.batch + k] = 0;
+}
+
+struct CutRoundArgs {
+    int n, m0, mstride, kc, batch, round, max_rounds;
+    double progress_tol, max_dual_bound;
+    const int32_t *status;         // dense node outputs of K1 / K4
+    const double *obj;
+    const int32_t *mipf;
+    const double *y;               // batch x mstride row duals
+    int8_t *vstat;                 // batch x (n + mstride): the nodes' current bases
+    int32_t *ncut, *ids;           // working cut lists
+    int32_t *state;                // CF_FIELDS x batch
+    double *obj_before;            // batch
+    int32_t *active;               // batch: in/out (still generating this round)
+    int32_t *resolve;              // batch: out, 1 where a cut was removed (the LP changed)
+    int32_t *counters;             // [n_active, n_changed, max_ncut, -]
+};
+// One wave per node.  round > 0: the stall test of the round just finished (base_node.py:320-324).
+// Then base_node.py:196-203's loop condition, and for the nodes that go on: clip (left to K2 / K3),
+// count the round, remember the objective, drop the cuts whose dual is exactly 0 (:326-341).
+__global__ __launch_bounds__(64) void cut_round_begin(CutRoundArgs g) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (k >= g.batch) return;
+    const size_t B = (size_t)g.batch;
+    const int st = g.status[k];
+    const bool lp_feasible = st == 0 || st == 2;
+    const double obj = lp_feasible ? g.obj[k] : __builtin_huge_val();
+    int stalled = g.state[CF_STALLED * B + k];
+    if (g.round > 0 && g.active[k]) {
+        const double before = g.obj_before[k];
+        if (fabs(before - obj) / fabs(before) < g.progress_tol) stalled = 1;   // (0/0: not stalled, as numpy)
+    }
+    const int rounds = g.state[CF_ROUNDS * B + k];
+    const bool act = lp_feasible && !g.mipf[k] && !stalled && rounds < g.max_rounds && obj < g.max_dual_bound;
+    int nc = g.ncut[k];
+    int nrem = 0;
+    if (act) {
+        int8_t *vs = g.vstat + (size_t)k * (g.n + g.mstride) + g.n + g.m0;
+        int32_t *ids = g.ids + (size_t)k * g.kc;
+        const bool mine = lane < nc;
+        const bool gone = mine && g.y[(size_t)k * g.mstride + g.m0 + lane] == 0.0;
+        const int id = mine ? ids[lane] : 0;
+        const int8_t code = mine ? vs[lane] : (int8_t)0;
+        const unsigned long long keep = __ballot(mine && !gone);
+        nrem = nc - __popcll(keep);
+        __builtin_amdgcn_wave_barrier();
+        if (mine && !gone) {
+            const int pos = __popcll(keep & ((1ull << lane) - 1ull));
+            ids[pos] = id;
+            vs[pos] = code;
+        }
+        nc -= nrem;
+    }
+    if (lane == 0) {
+        g.state[CF_STALLED * B + k] = stalled;
+        g.active[k] = act ? 1 : 0;
+        g.resolve[k] = (act && nrem > 0) ? 1 : 0;
+        if (act) {
+            g.state[CF_ROUNDS * B + k] = rounds + 1;
+            g.obj_before[k] = obj;
+            g.ncut[k] = nc;
+            if (nrem > 0) {
+                g.state[CF_IT_REMOVED * B + k] += 1;
+                g.state[CF_N_REMOVED * B + k] += nrem;
+            }
+            atomicAdd(&g.counters[0], 1);
+        }
+    }
+}
+
+struct PoolAppendArgs {
+    int batch, slab_rows;
+    const int32_t *active, *k2_ncuts;
+    int32_t *state, *pool_list;
+};
+// the cuts K2 just wrote to the node's slab join its pool, in row order (cut_pool = {**old, **new},
+// base_node.py:306) and are counted as created (:383)
+__global__ __launch_bounds__(64) void pool_append(PoolAppendArgs g) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= g.batch || !g.active[k]) return;
+    const size_t B = (size_t)g.batch;
+    const int made = g.k2_ncuts[k];
+    const int base = g.state[CF_SLAB_N * B + k];
+    const int kept = min(made, g.slab_rows - base);
+    const int pn = g.state[CF_POOL_N * B + k];
+    int32_t *pl = g.pool_list + (size_t)k * g.slab_rows;
+    for (int c = 0; c < kept; c++) pl[pn + c] = base + c;
+    g.state[CF_POOL_N * B + k] = pn + kept;
+    g.state[CF_SLAB_N * B + k] = base + kept;
+    if (made > kept) g.state[CF_DROPPED * B + k] += made - kept;
+    if (made > 0) {
+        g.state[CF_IT_CREATED * B + k] += 1;
+        g.state[CF_N_CREATED * B + k] += made;
+    }
+}
+
+struct CutApplyArgs {
+    int n, m0, mstride, kc, batch, slab_rows;
+    const int32_t *active;
+    const int32_t *k3_nadded, *k3_added;     // batch, batch x slab_rows (pool positions, in order)
+    const double *slab_pi, *slab_pi0;
+    int32_t *pool_list;
+    int8_t *vstat;
+    int32_t *ncut, *ids, *state;
+    double *store_pi, *store_pi0;            // the engine's cut store (append-only)
+    int32_t *store_count;
+    int store_cap;
+    int32_t *resolve;                        // in/out: 1 where the node's LP changed this round
+    int32_t *counters;                       // [n_active, n_changed, max_ncut, -]
+};
+// K3's selection, applied (base_node.py:456-463): every selected cut becomes a row of the node's LP --
+// a new entry of the cut store, appended to the node's list, its slack basic -- and leaves the pool.
+__global__ __launch_bounds__(256) void cut_round_apply(CutApplyArgs g) {
+    __shared__ int id_s;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    if (k >= g.batch || !g.active[k]) return;
+    const size_t B = (size_t)g.batch;
+    const int nadd = g.k3_nadded[k];
+    int32_t *pl = g.pool_list + (size_t)k * g.slab_rows;
+    const int32_t *sel = g.k3_added + (size_t)k * g.slab_rows;
+    int nc = g.ncut[k];
+    int taken = 0;
+    for (int a = 0; a < nadd; a++) {
+        const int row = pl[sel[a]];
+        __syncthreads();
+        if (tid == 0) id_s = nc < g.kc ? atomicAdd(g.store_count, 1) : -1;
+        __syncthreads();
+        const int id = id_s;
+        if (id < 0 || id >= g.store_cap) continue;   // the node's list or the store is full: the cut is dropped
+        const double *src = g.slab_pi + ((size_t)k * g.slab_rows + row) * g.n;
+        double *dst = g.store_pi + (size_t)id * g.n;
+        for (int j = tid; j < g.n; j += 256) dst[j] = src[j];
+        if (tid == 0) {
+            g.store_pi0[id] = g.slab_pi0[(size_t)k * g.slab_rows + row];
+            g.ids[(size_t)k * g.kc + nc] = id;
+            g.vstat[(size_t)k * (g.n + g.mstride) + g.n + g.m0 + nc] = 1;   // a new row enters with its slack basic
+        }
+        nc++;
+        taken++;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // the pool keeps its order without the selected entries (del self.cut_pool[idx])
+        const int pn = g.state[CF_POOL_N * B + k];
+        for (int a = 0; a < nadd; a++) pl[sel[a]] = -1;
+        int w = 0;
+        for (int q = 0; q < pn; q++)
+            if (pl[q] >= 0) pl[w++] = pl[q];
+        g.state[CF_POOL_N * B + k] = w;
+        g.ncut[k] = nc;
+        g.state[CF_NCUT_OUT * B + k] = nc;
+        if (nadd > 0) {
+            g.state[CF_IT_ADDED * B + k] += 1;
+            g.state[CF_N_ADDED * B + k] += nadd;
+        }
+        if (nadd > taken) g.state[CF_DROPPED * B + k] += nadd - taken;
+        const int changed = g.resolve[k] | (taken > 0 ? 1 : 0);
+        g.resolve[k] = changed;
+        if (changed) atomicAdd(&g.counters[1], 1);
+        atomicMax(&g.counters[2], nc);
+    }
 }
 
 }  // namespace mipx

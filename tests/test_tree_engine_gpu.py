@@ -154,8 +154,8 @@ def test_native_mode_argument_checks():
     m = std_model('small_branch')
     with pytest.raises(AssertionError, match='frontier_batch must be a positive integer'):
         BranchAndBound(m, gomory_cuts=False, frontier_batch=0)
-    with pytest.raises(AssertionError, match='needs gomory_cuts=False'):
-        BranchAndBound(m, frontier_batch=4)
+    with pytest.raises(AssertionError, match='gomory_cuts is boolean'):
+        BranchAndBound(m, frontier_batch=4, gomory_cuts=1)
 
     class Mine(BaseNode):
         pass
