@@ -362,6 +362,77 @@ int mipx_tree_set_trace(mipx_tree *t, int on);
 int64_t mipx_tree_trace(mipx_tree *t, int64_t capacity, int64_t *node_id, int32_t *lp_status,
                         int32_t *branch_var, double *objective);
 
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, open nodes sharded, a best-first queue per rank.
+ * The reference is single-process (branch_and_bound.py:215-241): no counterpart.  The communicator
+ * binds RCCL (xGMI) directly -- librccl.so is loaded on first use, PyTorch is not involved.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mipx_comm mipx_comm;
+/* Rank 0 makes the id (ncclGetUniqueId), the launcher hands its 128 bytes to every rank. */
+int mipx_comm_unique_id(char id[128]);
+int mipx_comm_create_rccl(mipx_ctx *ctx, const char id[128], int rank, int world, mipx_comm **out);
+/* The same protocol over caller-supplied host-buffer primitives (0 = ok): the CPU tests and the
+ * one-GPU rehearsal plug a gloo process group in here (RCCL refuses two ranks on one device). */
+typedef struct mipx_comm_ops {
+    int (*allgather)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+    int (*send)(void *user, int peer, const void *buf, size_t bytes);
+    int (*recv)(void *user, int peer, void *buf, size_t bytes);
+} mipx_comm_ops;
+int mipx_comm_create_custom(mipx_ctx *ctx, int rank, int world, const mipx_comm_ops *ops, void *user,
+                            mipx_comm **out);
+void mipx_comm_destroy(mipx_comm *c);
+int mipx_comm_rank(const mipx_comm *c);
+int mipx_comm_size(const mipx_comm *c);
+/* HOST buffers; blocking.  (The engine's own exchange posts its all-gather and collects it later.) */
+int mipx_comm_allgather(mipx_comm *c, const void *send, void *recv, size_t bytes_per_rank);
+int mipx_comm_barrier(mipx_comm *c);
+
+/*
+ * Attach a communicator to a tree that has run the replicated ramp-up and kept its shard
+ * (mipx_tree_keep_shard).  From then on mipx_tree_solve is a COLLECTIVE call: every rank must call it.
+ * Every `every_steps` frontier steps -- after the next step's kernels are queued -- a rank collects
+ * the all-gather it posted last time and posts the next: one record per rank with its incumbent
+ * value and solution, the dual bound of its shard, its open-node count, its stop flag, its counters
+ * and its pseudo-cost samples (a running mean is sum-decomposable, pseudo_cost.py:97-98).  Applied:
+ *   - the best incumbent of any rank becomes everybody's (value AND solution: the reference's
+ *     contract is objective_value and solution, branch_and_bound.py:236-241);
+ *   - the merged pseudo-cost table;
+ *   - termination, decided identically by all ranks from the same records: every rank idle (no open
+ *     node anywhere), the global gap |primal - min dual| / |primal| <= mip_gap, or any rank's limit
+ *     (node_limit, max_seconds, max_steps count per rank);
+ *   - migration: a rank that cannot fill a batch gets half the surplus of the fullest rank (node
+ *     records move by ncclSend / ncclRecv; not with cut rounds).
+ * A rank without open nodes blocks in the exchange until work or the end arrives.  After the solve
+ * mipx_tree_get_stats / mipx_tree_solution report the GLOBAL incumbent on every rank;
+ * mipx_tree_global_stats adds the summed counters.
+ */
+int mipx_tree_set_comm(mipx_tree *t, mipx_comm *c, int every_steps);
+/* What every rank concludes from one gathered set of records -- a pure function of the records (no
+ * GPU involved), exposed so that the decision logic can be tested across real processes on the CPU.
+ * A record is mipx_exchange_record_len(n) doubles: [0] incumbent value, [1] dual bound of the shard,
+ * [2] open nodes (queued + in flight), [3] stop flag, [4..7] evaluated / LPs / probes / pivots since
+ * sharding, [8] 1 if the rank holds a solution for [0], [9] exchange number, [10] its frontier batch,
+ * [16..16+n) the solution, then 4 n pseudo-cost samples (sum_l, sum_r, times_l, times_r).
+ * reason: 0 go on, 1 no open node anywhere, 2 a rank's stop flag, 3 global gap <= mip_gap.
+ * moves: n_moves triples (from rank, to rank, node records), in the order they are carried out. */
+typedef struct mipx_exchange_decision {
+    double primal, dual, gap;
+    int64_t sums[4], open_nodes;
+    int32_t incumbent_rank, done, reason, n_moves;
+    int32_t moves[3 * 64];
+} mipx_exchange_decision;
+int mipx_exchange_record_len(int n);
+int mipx_exchange_decide(int world, int n, const double *records, double mip_gap, int allow_migration,
+                         mipx_exchange_decision *out);
+typedef struct mipx_tree_global_stats_t {
+    double primal_bound, dual_bound, gap;   /* gap: -1 encodes None */
+    int64_t evaluated_nodes;                /* ramp-up (replicated: counted once) + every rank's since sharding */
+    int64_t lp_solved, probes_solved, pivots, open_nodes;
+    int64_t exchanges, nodes_sent, nodes_received;   /* of this rank */
+    int32_t world, incumbent_rank;          /* rank whose solution everybody holds (-1: none) */
+} mipx_tree_global_stats_t;
+int mipx_tree_global_stats(mipx_tree *t, mipx_tree_global_stats_t *out);
+
 /* Name of the kernel instantiation that (m, n) dispatches to, e.g. "lp_dual_simplex<7,5,16>". */
 int mipx_kernel_name(int m, int n, char *buf, size_t buflen);
 

@@ -21,7 +21,10 @@ SYMBOLS = [
     'mipx_tree_set_anchor_mode',
     'mipx_lp_solve_batch', 'mipx_lp_solve_batch_dev', 'mipx_lp_solve_multi', 'mipx_gomory_batch', 'mipx_cut_select_batch',
     'mipx_safe_cut_batch', 'mipx_get_fraction_batch', 'mipx_lp_solve_batch_cuts', 'mipx_tree_create_ex',
-    'mipx_tree_cut_stats', 'mipx_dev_alloc', 'mipx_dev_free',
+    'mipx_tree_cut_stats', 'mipx_comm_unique_id', 'mipx_comm_create_rccl', 'mipx_comm_create_custom',
+    'mipx_comm_destroy', 'mipx_comm_rank', 'mipx_comm_size', 'mipx_comm_allgather', 'mipx_comm_barrier',
+    'mipx_tree_set_comm', 'mipx_tree_global_stats', 'mipx_exchange_record_len', 'mipx_exchange_decide',
+    'mipx_dev_alloc', 'mipx_dev_free',
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
     'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
@@ -68,6 +71,50 @@ class CutParams(C.Structure):
 CUT_TOTAL_KEYS = ('total_cut_generation_iterations', 'total_iterations_gmic_created',
                   'total_number_gmic_created', 'total_iterations_gmic_added', 'total_number_gmic_added',
                   'total_iterations_gmic_removed', 'total_number_gmic_removed')
+
+class GlobalStats(C.Structure):
+    """mipx_tree_global_stats_t (include/mipx.h)."""
+    _fields_ = [('primal_bound', C.c_double), ('dual_bound', C.c_double), ('gap', C.c_double),
+                ('evaluated_nodes', C.c_int64), ('lp_solved', C.c_int64), ('probes_solved', C.c_int64),
+                ('pivots', C.c_int64), ('open_nodes', C.c_int64), ('exchanges', C.c_int64),
+                ('nodes_sent', C.c_int64), ('nodes_received', C.c_int64), ('world', C.c_int32),
+                ('incumbent_rank', C.c_int32)]
+
+
+class ExchangeDecision(C.Structure):
+    """mipx_exchange_decision (include/mipx.h)."""
+    _fields_ = [('primal', C.c_double), ('dual', C.c_double), ('gap', C.c_double), ('sums', C.c_int64 * 4),
+                ('open_nodes', C.c_int64), ('incumbent_rank', C.c_int32), ('done', C.c_int32),
+                ('reason', C.c_int32), ('n_moves', C.c_int32), ('moves', C.c_int32 * 192)]
+
+
+def exchange_record_len(n):
+    return lib().mipx_exchange_record_len(int(n))
+
+
+def exchange_decide(records, n, mip_gap=1e-4, allow_migration=True):
+    """What every rank concludes from the gathered records ((world, record_len) array): dict."""
+    records = np.ascontiguousarray(records, dtype=np.float64)
+    world = records.shape[0]
+    assert records.shape[1] == exchange_record_len(n)
+    d = ExchangeDecision()
+    L = lib()
+    L.mipx_exchange_decide.argtypes = [C.c_int, C.c_int, _vp, C.c_double, C.c_int, C.POINTER(ExchangeDecision)]
+    rc = L.mipx_exchange_decide(world, int(n), _ptr(records), float(mip_gap), int(bool(allow_migration)), C.byref(d))
+    if rc != MIPX_OK:
+        raise MipxError(f'mipx_exchange_decide failed: {ERRORS.get(rc, rc)}')
+    return dict(primal=d.primal, dual=d.dual, gap=None if d.gap < 0 else d.gap, sums=list(d.sums),
+                open_nodes=d.open_nodes, incumbent_rank=d.incumbent_rank, done=bool(d.done), reason=d.reason,
+                moves=[tuple(d.moves[3 * k:3 * k + 3]) for k in range(d.n_moves)])
+
+
+class CommOps(C.Structure):
+    """mipx_comm_ops: host-buffer primitives of a custom communicator."""
+    ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+    SEND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
+    RECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t)
+    _fields_ = [('allgather', ALLGATHER), ('send', SEND), ('recv', RECV)]
+
 
 TREE_STATUS = {0: 'unsolved', 1: 'optimal', 2: 'infeasible', 3: 'unbounded',
                4: 'stopped on iterations or time'}
@@ -133,6 +180,108 @@ def lib():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(_vp)
+
+
+def comm_unique_id():
+    """The 128 bytes rank 0 makes (ncclGetUniqueId) and the launcher hands to every rank."""
+    buf = C.create_string_buffer(128)
+    L = lib()
+    L.mipx_comm_unique_id.argtypes = [C.c_char_p]
+    rc = L.mipx_comm_unique_id(buf)
+    if rc != MIPX_OK:
+        raise MipxError(f'mipx_comm_unique_id failed: {ERRORS.get(rc, rc)} (librccl.so is needed for more than one GPU)')
+    return buf.raw
+
+
+class Comm:
+    """The communicator of a multi-GPU search (mipx_comm): RCCL over xGMI, bound in libmipx.so.
+
+    Comm(ctx, rank, world, unique_id=...) is the product; Comm(ctx, rank, world, allgather=, send=,
+    recv=) runs the same protocol over caller-supplied host-buffer primitives (tests / rehearsals:
+    allgather(send_bytes) -> list of world bytes objects, send(peer, bytes), recv(peer, nbytes) ->
+    bytes)."""
+
+    def __init__(self, ctx, rank, world, unique_id=None, allgather=None, send=None, recv=None):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        L = lib()
+        h = _vp()
+        if unique_id is not None:
+            assert len(unique_id) == 128, 'the RCCL unique id has 128 bytes'
+            L.mipx_comm_create_rccl.argtypes = [_vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]
+            rc = L.mipx_comm_create_rccl(ctx._h, unique_id, self.rank, self.world, C.byref(h))
+            ctx.check(rc, 'mipx_comm_create_rccl')
+            self.transport = 'rccl'
+        else:
+            self._err = None
+
+            def guard(fn):
+                def inner(*a):
+                    try:
+                        fn(*a)
+                        return 0
+                    except BaseException as e:   # never unwind through the C frames
+                        self._err = e
+                        return 1
+                return inner
+
+            def c_allgather(_user, sendp, recvp, nbytes):
+                parts = allgather(C.string_at(sendp, nbytes))
+                assert len(parts) == self.world and all(len(p) == nbytes for p in parts)
+                C.memmove(recvp, b''.join(parts), nbytes * self.world)
+
+            def c_send(_user, peer, bufp, nbytes):
+                send(int(peer), C.string_at(bufp, nbytes))
+
+            def c_recv(_user, peer, bufp, nbytes):
+                data = recv(int(peer), int(nbytes))
+                assert len(data) == nbytes
+                C.memmove(bufp, data, nbytes)
+            self._ops = CommOps(CommOps.ALLGATHER(guard(c_allgather)), CommOps.SEND(guard(c_send)),
+                                CommOps.RECV(guard(c_recv)))
+            L.mipx_comm_create_custom.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(CommOps), _vp, C.POINTER(_vp)]
+            rc = L.mipx_comm_create_custom(None if ctx is None else ctx._h, self.rank, self.world,
+                                           C.byref(self._ops), None, C.byref(h))
+            if rc != MIPX_OK:
+                raise MipxError(f'mipx_comm_create_custom failed: {ERRORS.get(rc, rc)}')
+            self.transport = 'custom'
+        self._h = h
+
+    def check(self, rc, what):
+        err, self._err = getattr(self, '_err', None), None
+        if err is not None:
+            raise err
+        if self.ctx is not None:
+            self.ctx.check(rc, what)
+        elif rc != MIPX_OK:
+            raise MipxError(f'{what} failed: {ERRORS.get(rc, rc)}')
+
+    def allgather(self, arr):
+        """All-gather of one equally sized array per rank (host, blocking): (world, ...) array."""
+        arr = np.ascontiguousarray(arr)
+        out = np.zeros((self.world,) + arr.shape, arr.dtype)
+        L = lib()
+        L.mipx_comm_allgather.argtypes = [_vp, _vp, _vp, C.c_size_t]
+        self.check(L.mipx_comm_allgather(self._h, _ptr(arr), _ptr(out), arr.nbytes), 'mipx_comm_allgather')
+        return out
+
+    def barrier(self):
+        L = lib()
+        L.mipx_comm_barrier.argtypes = [_vp]
+        self.check(L.mipx_comm_barrier(self._h), 'mipx_comm_barrier')
+
+    def close(self):
+        if getattr(self, '_h', None) and (self.ctx is None or getattr(self.ctx, '_h', None)):
+            L = lib()
+            L.mipx_comm_destroy.argtypes = [_vp]
+            L.mipx_comm_destroy.restype = None
+            L.mipx_comm_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -464,6 +613,10 @@ class Tree:
         err, self._hook_error = getattr(self, '_hook_error', None), None
         if err is not None:  # raised inside the step hook: the engine stopped, re-raise it here
             raise err
+        comm = getattr(self, '_comm', None)
+        if comm is not None and getattr(comm, '_err', None) is not None:   # raised inside a transport callback
+            cerr, comm._err = comm._err, None
+            raise cerr
         self.problem.ctx.check(rc, 'mipx_tree_solve')
         return st.as_dict()
 
@@ -524,6 +677,21 @@ class Tree:
             self._hook = proto(trampoline)  # keep the thunk alive as long as it is installed
             rc = L.mipx_tree_set_step_hook(self._h, self._hook, None, int(every_steps))
         self.problem.ctx.check(rc, 'mipx_tree_set_step_hook')
+
+    def set_comm(self, comm, every_steps=5):
+        """Attach the communicator: solve() becomes a collective call (mipx_tree_set_comm)."""
+        L = lib()
+        L.mipx_tree_set_comm.argtypes = [_vp, _vp, C.c_int]
+        self._comm = comm
+        self.problem.ctx.check(L.mipx_tree_set_comm(self._h, None if comm is None else comm._h, int(every_steps)),
+                               'mipx_tree_set_comm')
+
+    def global_stats(self):
+        st = GlobalStats()
+        L = lib()
+        L.mipx_tree_global_stats.argtypes = [_vp, C.POINTER(GlobalStats)]
+        self.problem.ctx.check(L.mipx_tree_global_stats(self._h, C.byref(st)), 'mipx_tree_global_stats')
+        return {k: getattr(st, k) for k, _ in st._fields_}
 
     def cut_stats(self):
         """The running GMIC totals of BaseNode._base_bound over every evaluated node (+ 'dropped')."""

@@ -122,7 +122,7 @@ class BranchAndBound(BaseAlgorithm):
 
     def __init__(self, model, Node=BaseNode, node_queue=None, node_limit=INF, mip_gap=.0001,
                  logging=False, max_run_time=INF, initial_primal_bound=INF, frontier_batch=None,
-                 pool_capacity=1 << 16, anchor=None, dive=None, **kwargs):
+                 pool_capacity=1 << 16, anchor=None, dive=None, comm=None, exchange_every=5, **kwargs):
         """All problems are converted to minimisation with A x >= b on the way in.  **kwargs are
         handed to every bound()/branch() call and refreshed from what those calls return
         (e.g. pseudo_costs={}, strong_branch_iters=5, gomory_cuts=False).
@@ -134,12 +134,20 @@ class BranchAndBound(BaseAlgorithm):
         With gomory_cuts=True (the reference's default, base_node.py:365) every node runs the cut
         rounds of BaseNode._base_bound inside the engine (register-tile shapes: m + 64 <= 192 rows,
         n <= 256; no dive then).  In this mode `tree` holds only the root (nodes live on the device).
+        comm (extension; needs frontier_batch): an _ffi.Comm shared by one process per GPU
+        (simple_mip_solver_amd.parallel.init_comm).  Every rank builds the same BranchAndBound and
+        calls solve(): after a replicated ramp-up the open nodes are sharded over the ranks, which
+        exchange incumbent (value and solution), bounds, pseudo costs and node records every
+        `exchange_every` steps over RCCL; every rank ends with the same status, objective_value and
+        solution; evaluated_nodes is the total over all ranks.
         anchor / dive (default: on for frontier_batch > 1, register-tile shapes): warm starts
         refactor from the root's optimal tableau instead of the slack basis; the workgroup that
         solved a node also solves one child on the tableau it holds (same optimum, another node
         order -- see DESIGN.md section 4)."""
         self._native = None
         self._native_stats = None
+        assert comm is None or frontier_batch is not None, 'comm needs frontier_batch'
+        self._comm, self._exchange_every, self._sharded = comm, exchange_every, False
         if frontier_batch is not None:
             assert isinstance(frontier_batch, int) and frontier_batch > 0, \
                 'frontier_batch must be a positive integer'
@@ -294,10 +302,23 @@ class BranchAndBound(BaseAlgorithm):
                 self._native.set_anchor_mode(True)
             if self._dive:
                 self._native.set_dive(True)
-        st = self._native.solve(node_limit=0 if self.node_limit == INF else self.node_limit,
-                                mip_gap=self.mip_gap,
-                                max_seconds=0.0 if self.max_run_time == INF else self.max_run_time,
-                                frontier_batch=self.frontier_batch)
+        st = None
+        if self._comm is not None and not self._sharded:
+            from simple_mip_solver_amd.parallel import shard_and_attach
+            ramp = shard_and_attach(self._native, self._comm, self.frontier_batch, self._exchange_every)
+            self._sharded = True
+            if ramp['status'] not in (0, 4) or ramp['open_nodes'] == 0:
+                st = ramp      # finished inside the replicated ramp-up: every rank holds the result
+                self._comm = None
+        if st is None:
+            st = self._native.solve(node_limit=0 if self.node_limit == INF else self.node_limit,
+                                    mip_gap=self.mip_gap,
+                                    max_seconds=0.0 if self.max_run_time == INF else self.max_run_time,
+                                    frontier_batch=self.frontier_batch)
+        if self._comm is not None:
+            g = self._native.global_stats()
+            st = dict(st, evaluated_nodes=g['evaluated_nodes'])
+            self._native_global = g
         self._native_stats = st
         if st['pool_exhausted']:
             import warnings

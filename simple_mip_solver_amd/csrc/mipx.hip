@@ -1,4 +1,4 @@
-// mipx.hip -- host side of the C ABI declared in include/mipx.h (HIP runtime only: no torch,
+// mipx.hip -- host side of the C ABI declared in include/mipx.h (HIP runtime only: no ML framework,
 // no BLAS).  One context = one GPU + one stream.  No CPU fallback exists: every entry point
 // that computes requires a live HIP device.
 #include <hip/hip_runtime.h>
@@ -163,6 +163,7 @@ int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t strea
 }  // namespace
 
 #include "cut_kernels.hip.h"
+#include "comm.hip.h"
 #include "tree_engine.hip.h"
 
 extern "C" {

@@ -281,6 +281,21 @@ struct mipx_tree {
     std::vector<double> tr_obj;
     bool trace = false;
     bool anchor_mode = false, anchor_set = false;
+    // multi-GPU exchange (mipx_tree_set_comm)
+    mipx_comm *comm = nullptr;
+    int x_every = 0;
+    bool x_done = false;             // the ranks agreed to stop (set by an applied exchange)
+    int x_stop_flag = 0;             // this rank hit one of its own limits
+    int64_t x_rounds = 0;            // exchanges applied
+    int x_batch = 1;                 // frontier batch of the running solve (what "cannot fill a batch" means)
+    double x_mip_gap = 0.0;
+    std::vector<double> x_rec;       // this rank's record
+    std::vector<double> pc_base, pc_own, pc_others;   // [sum_l | sum_r | times_l | times_r], n each
+    int64_t ramp[4] = {0, 0, 0, 0};  // evaluated, lps, probes, pivots at sharding time (replicated ramp-up)
+    int64_t g_counts[5] = {0, 0, 0, 0, 0};   // global evaluated, lps, probes, pivots, open
+    double g_dual = -std::numeric_limits<double>::infinity();
+    int g_inc_rank = -1;
+    int64_t nodes_sent = 0, nodes_received = 0;
     // cut rounds
     bool cuts = false;
     mipx_cut_params cp{};
@@ -314,14 +329,14 @@ double tree_open_min(mipx_tree *t) {
     return t->open_bounds.empty() ? inf : t->open_bounds.top().first;
 }
 
-double tree_dual_bound(mipx_tree *t) { return std::fmin(tree_open_min(t), t->closed_min); }
+double tree_dual_bound(mipx_tree *t) { return std::fmin(tree_open_min(t), t->closed_min); }   // (of this rank's shard)
 
 // reference current_gap (branch_and_bound.py:203-213); -1 encodes None
 double tree_gap(mipx_tree *t) {
     const double inf = std::numeric_limits<double>::infinity();
     const double p = t->primal;
     if (p == inf) return -1.0;  // (before the dual bound: that one scans a bucket of the open list)
-    const double d = tree_dual_bound(t);
+    const double d = t->comm ? t->g_dual : tree_dual_bound(t);   // (sharded: the ranks' MIN, as of the last exchange)
     if (p == 0 && d == 0) return 0.0;
     if (p == 0) return inf;
     return std::fabs(p - d) / std::fabs(p);
@@ -404,7 +419,7 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
 
 // Device -> host copies of the step loop go through the side stream, never the null stream: a
 // null-stream copy shares a hardware queue with whatever the runtime mapped there, and in a
-// process that also runs torch + RCCL that was the main stream with a 2 ms node-LP launch queued
+// process that also ran an ML framework's streams and RCCL that was the main stream with a 2 ms node-LP launch queued
 // (measured: ~1 ms per synchronous hipMemcpy, 18 ms per 20 steps).
 int tree_d2h(mipx_tree *t, void *dst, const void *src, size_t bytes) {
     HIP_TRY(t->ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, t->st2));
@@ -438,12 +453,15 @@ void pc_update(mipx_tree *t, int var, int dir, int lp_status, double objective, 
                double variable_change) {
     double &cost = dir ? t->cost_r[var] : t->cost_l[var];
     int32_t &times = dir ? t->times_r[var] : t->times_l[var];
+    const size_t n = (size_t)t->n;
     if (lp_status == 0 || lp_status == 3) {
         double bc = objective - dual_bound;
         if (bc < 0) bc = 0;
         cost = (cost * (double)times + bc / variable_change) / (double)(times + 1);
+        if (t->comm) t->pc_own[(dir ? n : 0) + (size_t)var] += bc / variable_change;   // this rank's samples, in sum form
     }
     times += 1;
+    if (t->comm) t->pc_own[(dir ? 3 * n : 2 * n) + (size_t)var] += 1.0;
     t->has_entry[var] = 1;
 }
 
@@ -1001,6 +1019,269 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     return MIPX_OK;
 }
 
+// ---- the exchange between the ranks of one search (mipx_tree_set_comm) --------------------------------
+constexpr int kRecHead = 16;         // doubles in front of a record's solution and pseudo-cost samples
+constexpr int64_t kMaxMigrate = 4096;  // node records per donation
+
+size_t x_rec_len(const mipx_tree *t) { return (size_t)kRecHead + 5 * (size_t)t->n; }
+
+int64_t tree_open_count(const mipx_tree *t) { return (int64_t)(t->use_bq ? t->bq.size() : t->heap.size()); }
+
+// this rank's state as one record: [primal, dual, open + in flight, stop flag, evaluated, lps, probes,
+// pivots (since sharding), has_x, round, frontier batch, ...] [x (n)] [own pseudo-cost samples (4 n)]
+void x_fill_record(mipx_tree *t) {
+    const size_t n = (size_t)t->n;
+    std::vector<double> &r = t->x_rec;
+    r.assign(x_rec_len(t), 0.0);
+    int64_t inflight = 0;
+    for (const StepBuf &S : t->buf)
+        if (S.in_flight) inflight += S.B;
+    r[0] = t->primal;
+    r[1] = tree_dual_bound(t);
+    r[2] = (double)(tree_open_count(t) + inflight);
+    r[3] = (double)t->x_stop_flag;
+    r[4] = (double)(t->evaluated - t->ramp[0]);
+    r[5] = (double)(t->lps - t->ramp[1]);
+    r[6] = (double)(t->probes - t->ramp[2]);
+    r[7] = (double)(t->pivots - t->ramp[3]);
+    r[8] = t->have_x ? 1.0 : 0.0;
+    r[9] = (double)t->x_rounds;
+    r[10] = (double)t->x_batch;
+    if (t->have_x) std::memcpy(r.data() + kRecHead, t->best_x.data(), n * 8);
+    std::memcpy(r.data() + kRecHead + n, t->pc_own.data(), 4 * n * 8);
+}
+
+// A donation: `amount` node records from rank `from` to rank `to` (decided from the same records on
+// every rank).  The donor gives every second of its best 2 * amount open nodes, so that both keep
+// good ones; fewer if it has consumed them since it posted (the message has the planned size, a
+// count in front says how many records are real).
+int x_migrate(mipx_tree *t, int from, int to, int64_t amount) {
+    mipx_comm *c = t->comm;
+    mipx_ctx *ctx = t->ctx;
+    const int me = c->rank;
+    if (me != from && me != to) return MIPX_OK;
+    const size_t n = (size_t)t->n, nvs = n + (size_t)t->mrows;
+    const size_t rowbytes = 16 * n + (nvs + 7) / 8 * 8;
+    const size_t meta_off = (size_t)amount * rowbytes, bytes = meta_off + (1 + 5 * (size_t)amount) * 8;
+    char *msg = nullptr;
+    int rc = comm_msg_buffer(c, bytes + (size_t)amount * 4, &msg);   // (+ the slot list of the pack kernels)
+    if (rc) return rc;
+    int32_t *d_slots = (int32_t *)(msg + bytes);
+    std::vector<double> meta(1 + 5 * (size_t)amount, 0.0);
+    std::vector<int32_t> slots;
+    mipx::PackArgs pa;
+    pa.n = (int)n; pa.nvs = (int)nvs; pa.rowbytes = rowbytes; pa.slot = d_slots;
+    pa.pool_l = t->pool_l; pa.pool_u = t->pool_u; pa.pool_v = t->pool_v; pa.msg = msg;
+    if (me == from) {
+        const int64_t have = tree_open_count(t);
+        const int64_t give = std::max<int64_t>(0, std::min<int64_t>(amount, (have - t->x_batch) / 2));
+        std::vector<int64_t> ids;
+        if (t->use_bq) {
+            t->popped.clear();
+            t->bq.pop_batch((size_t)(2 * give), t->popped);
+            for (const auto &it : t->popped) ids.push_back(it.id);
+        } else {
+            for (int64_t k = 0; k < 2 * give && !t->heap.empty(); k++) ids.push_back(t->heap.pop());
+        }
+        int64_t cnt = 0;
+        for (size_t k = 0; k < ids.size(); k++) {
+            NodeRec &nd = t->nodes[ids[k]];
+            if (t->search != 0) t->is_open[ids[k]] = 0;
+            if ((k & 1) == 0 || cnt >= give) { tree_push(t, ids[k]); continue; }   // kept
+            double *mrec = meta.data() + 1 + 5 * cnt;
+            mrec[0] = nd.dual_bound; mrec[1] = nd.b_val; mrec[2] = (double)nd.depth;
+            mrec[3] = (double)nd.b_idx; mrec[4] = (double)nd.b_dir;
+            slots.push_back(nd.slot);
+            nd.slot = -1;
+            cnt++;
+        }
+        meta[0] = (double)cnt;
+        if (cnt > 0) {
+            HIP_TRY(ctx, hipMemcpyAsync(d_slots, slots.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, t->st2));
+            pa.count = (int)cnt;
+            hipLaunchKernelGGL(mipx::pack_nodes, dim3((unsigned)cnt), dim3(256), 0, t->st2, pa);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(msg + meta_off, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, t->st2));
+        HIP_TRY(ctx, hipStreamSynchronize(t->st2));
+        if ((rc = comm_send_dev(c, to, msg, bytes))) return rc;
+        for (int32_t sl : slots) t->free_slots.push_back(sl);
+        t->nodes_sent += cnt;
+    } else {
+        if ((rc = comm_recv_dev(c, from, msg, bytes))) return rc;
+        HIP_TRY(ctx, hipMemcpy(meta.data(), msg + meta_off, meta.size() * 8, hipMemcpyDeviceToHost));
+        const int64_t cnt = (int64_t)meta[0];
+        if (cnt < 0 || cnt > amount) return fail(ctx, MIPX_EHIP, "tree: corrupt migration message");
+        if ((int64_t)t->free_slots.size() < cnt + 4 * (int64_t)t->max_batch)
+            return fail(ctx, MIPX_ENOMEM, "tree: node pool too small for the migrated nodes (raise pool_capacity)");
+        for (int64_t k = 0; k < cnt; k++) {
+            const double *mrec = meta.data() + 1 + 5 * k;
+            NodeRec nd;
+            nd.dual_bound = mrec[0]; nd.b_val = mrec[1]; nd.depth = (int32_t)mrec[2];
+            nd.b_idx = (int32_t)mrec[3]; nd.b_dir = (int32_t)mrec[4];
+            nd.key = t->search == 0 ? nd.dual_bound : -(double)nd.depth;
+            nd.anchor = -1; nd.born = (int32_t)t->steps; nd.ncut = 0;
+            nd.slot = t->free_slots.back();
+            t->free_slots.pop_back();
+            slots.push_back(nd.slot);
+            t->nodes.push_back(nd);
+            tree_push(t, (int64_t)t->nodes.size() - 1);
+        }
+        if (cnt > 0) {
+            HIP_TRY(ctx, hipMemcpyAsync(d_slots, slots.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, t->st2));
+            pa.count = (int)cnt;
+            hipLaunchKernelGGL(mipx::unpack_nodes, dim3((unsigned)cnt), dim3(256), 0, t->st2, pa);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipStreamSynchronize(t->st2));
+        }
+        t->nodes_received += cnt;
+    }
+    return MIPX_OK;
+}
+
+// What every rank concludes from one gathered set of records -- a pure function of the records, so
+// that all ranks conclude the same (exposed as mipx_exchange_decide for the CPU tests).
+void x_decide(int W, int n, const double *records, double mip_gap, bool allow_migration,
+              mipx_exchange_decision *out) {
+    const size_t len = (size_t)kRecHead + 5 * (size_t)n;
+    const double inf = std::numeric_limits<double>::infinity();
+    auto rec = [&](int r) { return records + (size_t)r * len; };
+    // incumbent: the best value of any rank, and the lowest rank that holds a solution for it
+    double best = inf, dual = inf;
+    int who = -1;
+    int64_t sums[5] = {0, 0, 0, 0, 0};
+    bool any_stop = false;
+    for (int r = 0; r < W; r++) {
+        const double *q = rec(r);
+        if (q[0] < best) best = q[0];
+        dual = std::fmin(dual, q[1]);
+        sums[0] += (int64_t)q[4]; sums[1] += (int64_t)q[5]; sums[2] += (int64_t)q[6]; sums[3] += (int64_t)q[7];
+        sums[4] += (int64_t)q[2];
+        any_stop |= q[3] != 0.0;
+    }
+    for (int r = 0; r < W && who < 0; r++)
+        if (rec(r)[0] == best && rec(r)[8] != 0.0 && best < inf) who = r;
+    double gap = -1.0;   // reference current_gap (branch_and_bound.py:203-213); -1 encodes None
+    if (best < inf) {
+        if (best == 0 && dual == 0) gap = 0.0;
+        else if (best == 0) gap = inf;
+        else gap = std::fabs(best - dual) / std::fabs(best);
+    }
+    out->primal = best; out->dual = dual; out->gap = gap; out->incumbent_rank = who;
+    for (int k = 0; k < 4; k++) out->sums[k] = sums[k];
+    out->open_nodes = sums[4];
+    out->reason = sums[4] == 0 ? 1 : any_stop ? 2 : (gap >= 0 && gap <= mip_gap) ? 3 : 0;
+    out->done = out->reason != 0;
+    out->n_moves = 0;
+    // migration: a rank that cannot fill a batch gets half the surplus of the fullest rank
+    if (!out->done && allow_migration && W > 1) {
+        std::vector<int64_t> open((size_t)W), low((size_t)W);
+        for (int r = 0; r < W; r++) { open[(size_t)r] = (int64_t)rec(r)[2]; low[(size_t)r] = std::max<int64_t>(1, (int64_t)rec(r)[10]); }
+        for (int d = 0; d < W && out->n_moves < 64; d++) {
+            if (open[(size_t)d] >= low[(size_t)d]) continue;
+            int src = 0;
+            for (int r = 1; r < W; r++)
+                if (open[(size_t)r] > open[(size_t)src]) src = r;
+            if (src == d || open[(size_t)src] < 2 * low[(size_t)src]) continue;
+            const int64_t amount = std::min<int64_t>((open[(size_t)src] - open[(size_t)d]) / 2, kMaxMigrate);
+            if (amount <= 0) continue;
+            int32_t *mv = out->moves + 3 * out->n_moves++;
+            mv[0] = src; mv[1] = d; mv[2] = (int32_t)amount;
+            open[(size_t)src] -= amount;
+            open[(size_t)d] += amount;
+        }
+    }
+}
+
+// Apply one gathered set of records (identical on every rank).  last: the closing exchange -- merge
+// only, no decisions.
+int x_apply(mipx_tree *t, const char *gathered, bool last) {
+    const mipx_comm *c = t->comm;
+    const int W = c->world, me = c->rank;
+    const size_t n = (size_t)t->n, len = x_rec_len(t);
+    const double inf = std::numeric_limits<double>::infinity();
+    auto rec = [&](int r) { return (const double *)(gathered + (size_t)r * len * 8); };
+    mipx_exchange_decision D;
+    x_decide(W, t->n, (const double *)gathered, t->x_mip_gap, !t->cuts, &D);
+    const double best = D.primal;
+    const int who = D.incumbent_rank;
+    if (best < t->primal || (best == t->primal && best < inf && !t->have_x && who >= 0)) {
+        t->primal = best;
+        if (who >= 0) {
+            std::memcpy(t->best_x.data(), rec(who) + kRecHead, n * 8);
+            t->have_x = true;
+        }
+    }
+    if (t->primal == best) t->g_inc_rank = (t->primal < inf && who >= 0) ? who : (t->have_x && t->primal < inf ? me : -1);
+    else t->g_inc_rank = t->have_x ? me : -1;   // (this rank found a better one since it posted)
+    t->g_dual = D.dual;
+    for (int k = 0; k < 4; k++) t->g_counts[k] = t->ramp[k] + D.sums[k];
+    t->g_counts[4] = D.open_nodes;
+    // pseudo costs: what all ranks agreed on at sharding time + every other rank's samples as of its
+    // record + this rank's own samples as of now
+    if (t->rule == 1) {
+        std::fill(t->pc_others.begin(), t->pc_others.end(), 0.0);
+        for (int r = 0; r < W; r++) {
+            if (r == me) continue;
+            const double *o = rec(r) + kRecHead + n;
+            for (size_t j = 0; j < 4 * n; j++) t->pc_others[j] += o[j];
+        }
+        for (size_t j = 0; j < n; j++) {
+            const double tl = t->pc_base[2 * n + j] + t->pc_others[2 * n + j] + t->pc_own[2 * n + j];
+            const double tr = t->pc_base[3 * n + j] + t->pc_others[3 * n + j] + t->pc_own[3 * n + j];
+            const double sl = t->pc_base[j] + t->pc_others[j] + t->pc_own[j];
+            const double sr = t->pc_base[n + j] + t->pc_others[n + j] + t->pc_own[n + j];
+            t->times_l[j] = (int32_t)tl; t->times_r[j] = (int32_t)tr;
+            t->cost_l[j] = tl > 0 ? sl / tl : 0.0;
+            t->cost_r[j] = tr > 0 ? sr / tr : 0.0;
+            t->has_entry[j] = (tl > 0 || tr > 0) ? 1 : 0;
+        }
+        t->table_dirty = true;
+    }
+    t->x_rounds++;
+    if (last) return MIPX_OK;
+    if (D.done) {   // every rank idle, a rank's limit, or the global gap: the same on every rank
+        t->x_done = true;
+        return MIPX_OK;
+    }
+    for (int k = 0; k < D.n_moves; k++) {
+        const int rc = x_migrate(t, D.moves[3 * k], D.moves[3 * k + 1], D.moves[3 * k + 2]);
+        if (rc) return rc;
+    }
+    return MIPX_OK;
+}
+
+// One call at an exchange point.  Collects the all-gather posted last time (by then long finished on
+// a busy rank) and posts the next; a rank with nothing to do (blocking) waits for that one as well.
+int x_tick(mipx_tree *t, bool blocking) {
+    mipx_comm *c = t->comm;
+    const char *g = nullptr;
+    int rc;
+    if (c->pending) {
+        if ((rc = comm_collect(c, &g))) return rc;
+        if ((rc = x_apply(t, g, false))) return rc;
+        if (t->x_done) return MIPX_OK;
+    }
+    x_fill_record(t);
+    if ((rc = comm_post(c, t->x_rec.data(), x_rec_len(t) * 8))) return rc;
+    if (blocking) {
+        if ((rc = comm_collect(c, &g))) return rc;
+        if ((rc = x_apply(t, g, false))) return rc;
+    }
+    return MIPX_OK;
+}
+
+// The closing exchange after the ranks agreed to stop: what each found since its last record.
+int x_close(mipx_tree *t) {
+    mipx_comm *c = t->comm;
+    const char *g = nullptr;
+    int rc;
+    x_fill_record(t);
+    if ((rc = comm_post(c, t->x_rec.data(), x_rec_len(t) * 8))) return rc;
+    if ((rc = comm_collect(c, &g))) return rc;
+    return x_apply(t, g, true);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1074,7 +1355,7 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
     rc |= dmalloc(ctx, &t->d_cost_l2, n); rc |= dmalloc(ctx, &t->d_cost_r2, n); rc |= dmalloc(ctx, &t->d_has2, n);
     // The side streams carry short, latency-critical work (probes, re-scoring, child records) that
     // must overtake the 2 ms node-LP launch queued on the main stream.  HIP multiplexes the streams
-    // of one priority onto a few hardware queues, so in a process that owns more streams (torch +
+    // of one priority onto a few hardware queues, so in a process that owns more streams (a framework +
     // RCCL in a multi-GPU rank) a normal-priority side stream can land behind the main stream's
     // queue; high-priority streams come from their own queue pool.
     int prio_least = 0, prio_greatest = 0;
@@ -1254,21 +1535,29 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
         t->started = true;
         tree_push(t, 0);
     }
-    int64_t steps = 0, hooked_at = 0;
+    int64_t steps = 0, hooked_at = 0, xchg_at = 0;
     bool hook_stop = false;
+    if (t->comm) {
+        t->x_mip_gap = mip_gap; t->x_batch = frontier_batch; t->x_stop_flag = 0; t->x_done = false;
+    }
     // With frontier batches > 1 the host half of step k (bookkeeping, children) overlaps the GPU
     // half of step k+1, whose batch is popped before the children of step k exist.
     const bool overlap = t->pipeline && frontier_batch > 1;
     int cur = 0;
-    auto stop_now = [&](int64_t inflight) {
-        if (t->unbounded || hook_stop) return true;
+    // this rank's own limits
+    auto limit_now = [&](int64_t inflight) {
+        if (t->unbounded || hook_stop || t->pool_exhausted) return true;
         if (node_limit > 0 && t->evaluated + inflight >= node_limit) return true;
-        const double gap = tree_gap(t);
-        if (gap >= 0 && gap <= mip_gap) return true;
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (max_seconds > 0 && el > max_seconds) return true;
         if (max_steps > 0 && steps >= max_steps) return true;
         return false;
+    };
+    auto stop_now = [&](int64_t inflight) {
+        if (limit_now(inflight)) return true;
+        if (t->comm) return t->x_done;   // (the gap is the ranks' joint decision: x_apply)
+        const double gap = tree_gap(t);
+        return gap >= 0 && gap <= mip_gap;
     };
     auto batch_size = [&](int64_t inflight) {
         int64_t want = frontier_batch;
@@ -1288,6 +1577,7 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
         }
         return (int)want;
     };
+    for (;;) {
     if (!tree_queue_empty(t) && !stop_now(0)) {
         int rc = tree_launch(t, t->buf[cur], batch_size(0));
         if (rc) return rc;
@@ -1308,6 +1598,11 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
             hooked_at = steps;  // the GPU is busy with the queued steps while the ranks exchange
             if (t->hook(t->hook_user)) hook_stop = true;
         }
+        if (t->comm && steps > 0 && steps % t->x_every == 0 && steps != xchg_at) {
+            xchg_at = steps;  // collect the exchange posted x_every steps ago, post the next
+            const int xrc = x_tick(t, false);
+            if (xrc) return xrc;
+        }
         int rc = tree_finish(t, S, overlap);
         if (rc) return rc;
         if (!N.in_flight && !tree_queue_empty(t) && !stop_now(0)) {
@@ -1317,8 +1612,21 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
         }
         if (overlap) cur = 1 - cur;
     }
+    if (!t->comm || t->x_done) break;
+    // Nothing in flight: out of open nodes, or at one of this rank's limits.  The other ranks may
+    // still work: wait for them in the exchange (it blocks until every rank has posted), where open
+    // nodes may arrive from a fuller rank or the joint decision to stop is taken.
+    t->x_stop_flag = limit_now(0) ? 1 : 0;
+    const int xrc = x_tick(t, true);
+    if (xrc) return xrc;
+    if (t->x_done) break;
+    }
     HIP_TRY(ctx, hipStreamSynchronize(t->st3));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (t->comm) {
+        const int xrc = x_close(t);
+        if (xrc) return xrc;
+    }
     t->solve_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("MIPX_TREE_PROFILE")) {
         const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1334,9 +1642,10 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
         std::fprintf(stderr, "[mipx_tree]   probes: read-back %.2f  enqueue %.2f  wait %.2f  results %.2f\n",
                      t->probe_ms[0] - pr0[0], t->probe_ms[1] - pr0[1], t->probe_ms[2] - pr0[2], t->probe_ms[3] - pr0[3]);
     }
-    const double gap = tree_gap(t);
+    const double gap = tree_gap(t);   // (with a communicator: of the global bounds)
+    const bool nothing_open = t->comm ? t->g_counts[4] == 0 : tree_queue_empty(t);
     if (t->unbounded) t->status = 3;
-    else if (tree_queue_empty(t) && t->primal == inf) t->status = 2;
+    else if (nothing_open && t->primal == inf) t->status = 2;
     else if (t->primal < inf && gap >= 0 && gap <= mip_gap) t->status = 1;
     else t->status = 4;
     if (out) mipx_tree_get_stats(t, out);
@@ -1433,7 +1742,7 @@ int mipx_tree_get_stats(mipx_tree *t, mipx_tree_stats *out) {
     out->created_nodes = (int64_t)t->nodes.size();
     out->steps = t->steps;
     out->primal_bound = t->primal;
-    out->dual_bound = tree_dual_bound(t);
+    out->dual_bound = t->comm ? t->g_dual : tree_dual_bound(t);
     out->gap = tree_gap(t);
     out->solve_seconds = t->solve_seconds;
     out->kernel_ms = t->kernel_ms;
@@ -1442,6 +1751,61 @@ int mipx_tree_get_stats(mipx_tree *t, mipx_tree_stats *out) {
     out->dives = t->dives;
     out->pool_exhausted = t->pool_exhausted ? 1 : 0;
     out->reserved = 0;
+    return MIPX_OK;
+}
+
+int mipx_exchange_record_len(int n) { return n > 0 ? kRecHead + 5 * n : MIPX_EINVAL; }
+
+int mipx_exchange_decide(int world, int n, const double *records, double mip_gap, int allow_migration,
+                         mipx_exchange_decision *out) {
+    if (world < 1 || n < 1 || !records || !out) return MIPX_EINVAL;
+    x_decide(world, n, records, mip_gap, allow_migration != 0, out);
+    return MIPX_OK;
+}
+
+int mipx_tree_set_comm(mipx_tree *t, mipx_comm *c, int every_steps) {
+    if (!t || (c && every_steps < 1)) return MIPX_EINVAL;
+    if (c && c->ctx != t->ctx) return fail(t->ctx, MIPX_EINVAL, "mipx_tree_set_comm: communicator of another context");
+    t->comm = c;
+    t->x_every = c ? every_steps : 0;
+    if (!c) return MIPX_OK;
+    const size_t n = (size_t)t->n;
+    // what every rank holds at sharding time (replicated ramp-up) is counted once
+    t->ramp[0] = t->evaluated; t->ramp[1] = t->lps; t->ramp[2] = t->probes; t->ramp[3] = t->pivots;
+    t->pc_base.assign(4 * n, 0.0);
+    t->pc_own.assign(4 * n, 0.0);
+    t->pc_others.assign(4 * n, 0.0);
+    for (size_t j = 0; j < n; j++) {
+        t->pc_base[j] = t->cost_l[j] * (double)t->times_l[j];
+        t->pc_base[n + j] = t->cost_r[j] * (double)t->times_r[j];
+        t->pc_base[2 * n + j] = (double)t->times_l[j];
+        t->pc_base[3 * n + j] = (double)t->times_r[j];
+    }
+    t->g_dual = tree_dual_bound(t);
+    for (int k = 0; k < 4; k++) t->g_counts[k] = t->ramp[k];
+    t->g_counts[4] = tree_open_count(t);
+    t->x_rounds = 0;
+    t->x_done = false;
+    return MIPX_OK;
+}
+
+int mipx_tree_global_stats(mipx_tree *t, mipx_tree_global_stats_t *out) {
+    if (!t || !out) return MIPX_EINVAL;
+    out->primal_bound = t->primal;
+    out->dual_bound = t->comm ? t->g_dual : tree_dual_bound(t);
+    out->gap = tree_gap(t);
+    if (t->comm) {
+        out->evaluated_nodes = t->g_counts[0]; out->lp_solved = t->g_counts[1];
+        out->probes_solved = t->g_counts[2]; out->pivots = t->g_counts[3]; out->open_nodes = t->g_counts[4];
+    } else {
+        out->evaluated_nodes = t->evaluated; out->lp_solved = t->lps; out->probes_solved = t->probes;
+        out->pivots = t->pivots; out->open_nodes = tree_open_count(t);
+    }
+    out->exchanges = t->x_rounds;
+    out->nodes_sent = t->nodes_sent;
+    out->nodes_received = t->nodes_received;
+    out->world = t->comm ? t->comm->world : 1;
+    out->incumbent_rank = t->comm ? t->g_inc_rank : (t->have_x ? 0 : -1);
     return MIPX_OK;
 }
 

@@ -157,6 +157,40 @@ __global__ __launch_bounds__(256) void make_children(ChildArgs g) {
     }
 }
 
+// ---- node migration between ranks (multi-GPU): pool rows <-> one contiguous message -----------------
+struct PackArgs {
+    int n, nvs, count;             // nvs: basis entries allotted per node (n + rows)
+    size_t rowbytes;               // 16 n + nvs rounded up to 8
+    const int32_t *slot;           // count pool rows
+    double *pool_l, *pool_u;
+    int8_t *pool_v;
+    char *msg;
+};
+__global__ __launch_bounds__(256) void pack_nodes(PackArgs g) {
+    const int k = blockIdx.x;
+    if (k >= g.count) return;
+    const size_t s = (size_t)g.slot[k];
+    double *row = (double *)(g.msg + (size_t)k * g.rowbytes);
+    for (int j = threadIdx.x; j < g.n; j += 256) {
+        row[j] = g.pool_l[s * g.n + j];
+        row[g.n + j] = g.pool_u[s * g.n + j];
+    }
+    int8_t *v = (int8_t *)(row + 2 * g.n);
+    for (int j = threadIdx.x; j < g.nvs; j += 256) v[j] = g.pool_v[s * g.nvs + j];
+}
+__global__ __launch_bounds__(256) void unpack_nodes(PackArgs g) {
+    const int k = blockIdx.x;
+    if (k >= g.count) return;
+    const size_t s = (size_t)g.slot[k];
+    const double *row = (const double *)(g.msg + (size_t)k * g.rowbytes);
+    for (int j = threadIdx.x; j < g.n; j += 256) {
+        g.pool_l[s * g.n + j] = row[j];
+        g.pool_u[s * g.n + j] = row[g.n + j];
+    }
+    const int8_t *v = (const int8_t *)(row + 2 * g.n);
+    for (int j = threadIdx.x; j < g.nvs; j += 256) g.pool_v[s * g.nvs + j] = v[j];
+}
+
 // ---- cut rounds inside the frontier engine (reference base_node.py:137-230, :292-341) ------------
 // Per node of the batch a working copy of its cut list (ids into the engine's cut store, at most 64)
 // and a few counters; the kernels below are the host-free parts of _base_bound's loop: who is still

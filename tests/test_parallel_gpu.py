@@ -1,77 +1,185 @@
-"""The RCCL path of the exchange on a real GPU: one rank (the pool's boxes have one GPU), the
-pinned-buffer / side-stream code of PipelinedExchange and the step hook with collectives inside."""
+"""The sharded search on a real GPU.
+
+(1) RCCL inside libmipx.so with one rank (the pool's boxes have one GPU): the communicator's
+    stream / pinned buffers / ncclAllGather, and mipx_tree_solve as a collective call -- same search
+    as without a communicator.
+(2) Two PROCESSES sharing the one GPU -- a rehearsal, never a measurement: RCCL refuses two ranks on
+    one device, so the very same protocol runs over the custom transport (gloo underneath,
+    tests/support/gloo_comm.py).  Two sharded engines reach the proven optimum AND the solution of
+    the single-rank run on a 40 x 16 instance; both ranks end with the same incumbent; a rank that
+    starts without open nodes is fed by the other (node records move); every rank's stop is the
+    joint decision.  The same through BranchAndBound(comm=...).
+No scaling curve exists until the driver's SCALE record does."""
 import os
 import subprocess
 import sys
 import textwrap
 
+import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from tests.test_parallel_cpu import ROOT, run_two_ranks
 
-WORKER = textwrap.dedent('''
-    import os, sys
-    sys.path.insert(0, {root!r})
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dev = torch.device('cuda', 0)
-    dist.init_process_group('nccl', device_id=dev)
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_one_rank_collective_solve():
     from simple_mip_solver_amd import _ffi
     from simple_mip_solver_amd.generators import random_dense_milp_arrays
-    from simple_mip_solver_amd.parallel import PipelinedExchange, exchange
-    INF = float('inf')
-    assert exchange(dist, dev, INF, -12.5, [3, 100]) == (INF, -12.5, [3, 100], 1)   # nobody holds an incumbent
-    assert exchange(dist, dev, -9.0, -9.5, [1, 1]) == (-9.0, -9.5, [1, 1], 0)
-    # the engine with the pipelined exchange inside its step loop (what bench.py does for N > 1)
+    ctx = _ffi.default_context()
+    comm = _ffi.Comm(ctx, 0, 1, unique_id=_ffi.comm_unique_id())
+    assert comm.transport == 'rccl'
+    got = comm.allgather(np.arange(7, dtype=np.float64))
+    assert got.shape == (1, 7) and np.array_equal(got[0], np.arange(7))
+    comm.barrier()
     n, m, B = 64, 32, 256
     A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=0)
-    ctx = _ffi.Context(0)
     prob = _ffi.Problem(ctx, A, b, c)
-    def run(with_hook):
+
+    def run(with_comm):
         t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=B, pool_capacity=1 << 16)
         t.set_anchor_mode(True); t.set_dive(True)
         st = t.stats()
         while st['open_nodes'] < B:
             st = t.solve(mip_gap=0.0, frontier_batch=64, max_steps=1)
         t.keep_shard(0, 1)
-        pe = PipelinedExchange(dist, dev, n, n_counters=1)
-        pe.start(*t.pseudo_cost_arrays())
-        calls = []
-        def hook():
-            s_ = t.stats()
-            got = pe.step(s_['primal_bound'], s_['dual_bound'], [s_['evaluated_nodes']], *t.pseudo_cost_arrays())
-            calls.append(got)
-            if got is not None:
-                assert got[0] >= s_['primal_bound'] and got[2][0] <= s_['evaluated_nodes']   # one rank: its own, one interval old
-                t.set_pseudo_cost_arrays(*got[3])
-        if with_hook:
-            t.set_step_hook(hook, 2)
+        if with_comm:
+            t.set_comm(comm, 2)
         st = t.solve(mip_gap=0.0, frontier_batch=B, max_steps=8)
-        t.set_step_hook(None)
-        if with_hook:
-            assert len(calls) == 4 and calls[0] is None and all(c is not None for c in calls[1:])
-            s_ = t.stats()
-            got = pe.drain(s_['primal_bound'], s_['dual_bound'], [s_['evaluated_nodes']], *t.pseudo_cost_arrays())
-            assert got[2] == [s_['evaluated_nodes']] and got[1] == s_['dual_bound']
-            # with one rank the merged table is the rank's own table (up to the mean <-> sum round trip)
-            own = t.pseudo_cost_arrays()
-            assert np.allclose(got[3][0], own[0], rtol=1e-12) and np.array_equal(got[3][2], own[2])
-        return st
-    a, b_ = run(False), run(True)
-    assert a['evaluated_nodes'] == b_['evaluated_nodes'] and abs(a['dual_bound'] - b_['dual_bound']) < 1e-6
-    dist.barrier()
+        return t, st
+    t0, a = run(False)
+    t1, b_ = run(True)
+    assert a['evaluated_nodes'] == b_['evaluated_nodes'] and a['steps'] == b_['steps']
+    assert abs(a['dual_bound'] - b_['dual_bound']) < 1e-6 and b_['status'] == 4
+    g = t1.global_stats()
+    # 8 steps, an exchange every 2: four in the loop (the first has nothing to collect), the one the
+    # rank waits in when its step limit is reached, the closing one
+    assert g['world'] == 1 and g['exchanges'] >= 4 and g['evaluated_nodes'] == b_['evaluated_nodes']
+    assert g['nodes_sent'] == g['nodes_received'] == 0
+    # one rank: the merged pseudo-cost table is its own (up to the mean <-> sum round trip)
+    own0, own1 = t0.pseudo_cost_arrays(), t1.pseudo_cost_arrays()
+    assert np.allclose(own0[0], own1[0], rtol=1e-12) and np.array_equal(own0[2], own1[2])
+    t1.set_comm(None)
+    # a tree run to the end: the decision to stop is the exchange's
+    A, b, c, l, u, ints = random_dense_milp_arrays(40, 16, seed=3)
+    prob = _ffi.Problem(ctx, A, b, c)
+    out = []
+    for with_comm in (False, True):
+        t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=16, pool_capacity=1 << 15)
+        t.set_anchor_mode(True); t.set_dive(True)
+        if with_comm:
+            t.solve(mip_gap=0.0, frontier_batch=16, max_steps=3)
+            t.set_comm(comm, 3)
+        st = t.solve(mip_gap=1e-4, frontier_batch=16)
+        out.append((st, t.solution()))
+        if with_comm:
+            g = t.global_stats()
+            assert g['incumbent_rank'] == 0 and g['open_nodes'] >= 0 and g['evaluated_nodes'] == st['evaluated_nodes']
+            t.set_comm(None)
+    (ref, xr), (st, x) = out
+    assert st['status'] == ref['status'] == 1 and abs(st['primal_bound'] - ref['primal_bound']) < 1e-9
+    assert abs(float(c @ x) - st['primal_bound']) < 1e-6 and abs(float(c @ xr) - ref['primal_bound']) < 1e-6
+
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import numpy as np
+    import torch.distributed as dist
+    dist.init_process_group('gloo')
+    os.environ['LOCAL_RANK'] = '0'                 # (one GPU on the box: both ranks use device 0)
+    from simple_mip_solver_amd import _ffi, BranchAndBound, PseudoCostBranchNode, MILPInstance
+    from simple_mip_solver_amd.generators import random_dense_milp_arrays
+    from simple_mip_solver_amd.parallel import shard_and_attach
+    from tests.support.gloo_comm import make_comm
+    rank = dist.get_rank()
+    ctx = _ffi.Context(0)                          # both ranks on the one GPU: a rehearsal
+    comm = make_comm(ctx)
+    n, m, B = 40, 16, 16
+    A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=3)
+    prob = _ffi.Problem(ctx, A, b, c)
+
+    def tree():
+        t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=B, pool_capacity=1 << 15)
+        t.set_anchor_mode(True); t.set_dive(True)
+        return t
+    one = tree()
+    ref = one.solve(mip_gap=1e-4, frontier_batch=B)
+    assert ref['status'] == 1
+    xref = one.solution()
+
+    # --- two sharded engines, the ordinary way ----------------------------------------------------
+    t = tree()
+    ramp = shard_and_attach(t, comm, B, exchange_every=3)
+    assert ramp['status'] == 4 and t.stats()['open_nodes'] >= B // 2
+    st = t.solve(mip_gap=1e-4, frontier_batch=B)
+    g = t.global_stats()
+    assert st['status'] == 1, st
+    assert abs(st['primal_bound'] - ref['primal_bound']) < 1e-9
+    x = t.solution()                                # every rank holds the incumbent SOLUTION
+    assert np.max(np.abs(x[ints] - np.round(x[ints]))) <= 1e-4 and np.all(A @ x >= b - 1e-6)
+    assert abs(float(c @ x) - st['primal_bound']) < 1e-6
+    both = comm.allgather(np.concatenate([[st['primal_bound'], st['dual_bound'], g['evaluated_nodes'], g['exchanges'],
+                                           g['incumbent_rank'], st['status']], x]))
+    assert np.array_equal(both[0], both[1]), both   # the same answer, bit for bit, on both ranks
+    assert g['world'] == 2 and g['evaluated_nodes'] >= ramp['evaluated_nodes']
+    moved = comm.allgather(np.array([g['nodes_sent'], g['nodes_received']], float))
+    assert moved[:, 0].sum() == moved[:, 1].sum()
+
+    # --- a rank that starts dry is fed by the other -------------------------------------------------
+    t = tree()
+    stx = t.stats()
+    while stx['open_nodes'] < 4 * B:
+        stx = t.solve(mip_gap=0.0, frontier_batch=B, max_steps=1)
+    if rank == 0:
+        t.keep_shard(0, 1)                          # everything
+    else:
+        t.keep_shard(999983, 1000003)               # nothing
+        assert t.stats()['open_nodes'] == 0
+    t.set_comm(comm, 3)
+    st = t.solve(mip_gap=1e-4, frontier_batch=B)
+    g = t.global_stats()
+    assert st['status'] == 1 and abs(st['primal_bound'] - ref['primal_bound']) < 1e-9
+    moved = comm.allgather(np.array([g['nodes_sent'], g['nodes_received'], st['evaluated_nodes']], float))
+    assert moved[0, 0] > 0 and moved[1, 1] == moved[0, 0] and moved[1, 0] == moved[0, 1] == 0
+    assert moved[1, 2] > stx['evaluated_nodes']     # the fed rank did evaluate nodes of its own
+    assert np.array_equal(t.solution(), comm.allgather(t.solution())[0])
+
+    # --- limits are joint decisions: one rank's step limit stops both -----------------------------
+    t = tree()
+    r2 = shard_and_attach(t, comm, B, exchange_every=2)
+    st = t.solve(mip_gap=0.0, frontier_batch=B, max_steps=[4, 1000][rank])
+    assert st['status'] == 4 and st['steps'] - r2['steps'] <= 12, st
+    t.set_comm(None)
+
+    # --- through the driver -----------------------------------------------------------------------
+    make = lambda: MILPInstance(A=A, b=b, c=c, l=l, u=u, sense=['Min', '>='], integerIndices=ints, numVars=n)
+    single = BranchAndBound(make(), PseudoCostBranchNode, pseudo_costs={{}}, gomory_cuts=False, frontier_batch=B)
+    single.solve()
+    bb = BranchAndBound(make(), PseudoCostBranchNode, pseudo_costs={{}}, gomory_cuts=False, frontier_batch=B,
+                        comm=make_comm(_ffi.default_context()), exchange_every=3)
+    bb.solve()
+    assert bb.status == single.status == 'optimal' and abs(bb.objective_value - single.objective_value) < 1e-9
+    assert bb.solution is not None and abs(float(c @ bb.solution) - bb.objective_value) < 1e-6
+    ev = comm.allgather(np.array([bb.evaluated_nodes, bb.objective_value], float))
+    assert np.array_equal(ev[0], ev[1]) and bb._native_global['world'] == 2
+    # with cut rounds the ranks still agree (no migration in that mode)
+    bc = BranchAndBound(make(), PseudoCostBranchNode, pseudo_costs={{}}, frontier_batch=B,
+                        comm=make_comm(_ffi.default_context()), exchange_every=3)
+    bc.solve()
+    assert bc.status == 'optimal' and bc.solution is not None
+    agree = comm.allgather(np.concatenate([[bc.objective_value], bc.solution]))
+    assert np.array_equal(agree[0], agree[1])
+    comm.barrier()
     dist.destroy_process_group()
-    print('rccl_ok')
+    sys.stdout.write('rank%dok\\n' % rank)
+    sys.stdout.flush()
 ''')
 
 
-def test_pipelined_exchange_over_rccl_one_rank(tmp_path):
+def test_two_processes_share_the_gpu_rehearsal(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', RANK='0', WORLD_SIZE='1',
-               LOCAL_RANK='0')
-    res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0 and 'rccl_ok' in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+    res = run_two_ranks(script, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-6000:]
+    assert 'rank0ok' in res.stdout and 'rank1ok' in res.stdout
