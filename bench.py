@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- node LP-relaxations/s on the C3 workload of BASELINE.md.
+"""bench.py -- node LP-relaxations/s (+ time-to-optimal leg) on the C3 workload of BASELINE.md.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): ONE 256 vars x
 128 rows random dense MILP (seed 0), PseudoCostBranchNode, best-first, pseudo_costs={},
-strong_branch_iters=5, gomory_cuts=False, solved by the native frontier engine
-(BranchAndBound(..., frontier_batch=B) -> mipx_tree_*): node records resident in HBM, every step
-= one frontier batch through the whole node hot path (LP relaxation to termination, strong-
-branching probes where the pseudo-cost table has no entry yet, pseudo-cost update, branching index,
-child materialisation).  Untimed: the ramp-up until every rank owns >= B open nodes, then W warm-up
-steps.  Timed: exactly K steps, barrier + device sync on both sides, MAX over ranks.
-value = node LP relaxations (solved to termination; probes are reported separately) per second,
-summed over ranks.
+strong_branch_iters=5, gomory_cuts=False, solved by the native frontier engine (mipx_tree_*): node
+records resident in HBM, every step = one frontier batch through the whole node hot path (LP
+relaxation to termination, strong-branching probes where the pseudo-cost table has no entry yet,
+pseudo-cost update, branching index, child materialisation).  Untimed: the ramp-up until every rank
+owns >= B open nodes, then W warm-up steps.  Timed: exactly K steps, barrier + device sync on both
+sides, MAX over ranks.  value = node LP relaxations (solved to termination; probes are reported
+separately) per second, summed over ranks.
 
-N > 1: all ranks run the same deterministic ramp-up, each keeps its share of the open nodes
-(Tree.keep_shard) and searches it with its own best-first queue; incumbent / global dual bound /
-counters are exchanged by all-reduce over RCCL every few steps (simple_mip_solver_amd/parallel.py).
+N > 1: `python bench.py --gpus N` spawns N processes (one per GPU; the driver's launcher form with
+RANK / WORLD_SIZE in the environment works too).  All ranks run the same deterministic ramp-up,
+each keeps its share of the open nodes and searches it with its own best-first queue; incumbent
+(value + solution), bounds, counters, pseudo-cost samples and -- when a shard runs dry -- node
+records are exchanged over RCCL from inside libmipx.so (no PyTorch anywhere in the product).
 Per-GPU frontier batch is fixed -> "weak" scaling.
+
+Also measured inside the run, after the timed region (rank 0): the other BASELINE configs (C2, C4,
+C5 single-GPU) under config.others, the time-to-optimal leg on the metric's own instance
+(depth-first: first incumbent, gap at a time limit) and the CPU baselines.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,10 +34,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from simple_mip_solver_amd import _ffi  # noqa: E402
-from simple_mip_solver_amd.generators import random_dense_milp_arrays  # noqa: E402
-from simple_mip_solver_amd.parallel import PipelinedExchange, exchange, global_gap  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 # f64 vector FMA: half the guide's 157.3 TFLOP/s f32 vector rate; scripts/microbench/prim.hip measures
@@ -48,67 +51,360 @@ def algorithmic_bytes(m, n, lps, pivots, dives=0):
     return (lps - dives) * load + lps * store + pivots * per_pivot
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=60)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8192, help='frontier nodes per step per GPU')
     ap.add_argument('--vars', type=int, default=256)
     ap.add_argument('--cons', type=int, default=128)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--cpu-seconds', type=float, default=12.0)
-    ap.add_argument('--cpu-threads', type=int, default=16, help='threads of the CPU baseline (over nodes)')
-    ap.add_argument('--exchange-every', type=int, default=5, help='steps between all-reduces (N > 1)')
+    ap.add_argument('--cpu-seconds', type=float, default=6.0, help='wall seconds of the CPU port baseline (0: skip)')
+    ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the CPU baseline; 0 = every CPU this process may use')
+    ap.add_argument('--highs-seconds', type=float, default=5.0, help='wall seconds of the HiGHS baseline B2 (0: skip)')
+    ap.add_argument('--tto-seconds', type=float, default=5.0, help='time limit of the time-to-optimal leg (0: skip)')
+    ap.add_argument('--others', type=int, default=1, choices=[0, 1], help='1: also measure C2, C4, C5 (config.others)')
+    ap.add_argument('--exchange-every', type=int, default=5, help='steps between exchanges (N > 1)')
     ap.add_argument('--dive', type=int, default=1, choices=[0, 1],
                     help='1: one-level plunge on the register tableau (mipx_tree_set_dive)')
     ap.add_argument('--reanchor', type=int, default=1, choices=[0, 1],
                     help='1: after sharding every open node gets an anchor of its own (mipx_tree_reanchor)')
     ap.add_argument('--no-anchor', action='store_true',
                     help='refactor every node from the slack basis instead of the root tableau')
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`bench.py --gpus N` from a plain shell: N fresh child processes, one per GPU, before this
+    process has touched the GPU (it never does).  Rank 0's JSON line is relayed; any failing child
+    fails the run."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        sys.stderr.write(f'bench.py: rank exit codes {codes}\n')
+        return 1
+    return 0
+
+
+def host_cpus():
+    """(logical CPUs of the host, physical cores, CPUs this process may run on, model name)."""
+    logical = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = logical
+    try:   # a cgroup quota narrows it further
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            usable = max(1, min(usable, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    cores, model, phys, core = set(), '', None, None
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name') and not model:
+                model = ln.split(':', 1)[1].strip()
+            elif ln.startswith('physical id'):
+                phys = ln.split(':', 1)[1].strip()
+            elif ln.startswith('core id'):
+                core = ln.split(':', 1)[1].strip()
+                cores.add((phys, core))
+    except Exception:
+        pass
+    return logical, len(cores) or logical, usable, model
+
+
+def cpu_port_baseline(args, tree, A, b, c, l, u, ints, B):
+    """B1: the oracle (the build's own C restatement of the path) on the very node LPs the GPU is about
+    to solve, OpenMP-style over nodes on every CPU this process may use."""
+    from oracle import oracle as O
+    from concurrent.futures import ThreadPoolExecutor
+    import contextlib
+    logical, physical, usable, model = host_cpus()
+    threads = args.cpu_threads if args.cpu_threads > 0 else usable
+    peek = 4 * B * (3 if threads > 4 else 1)
+    L, U, V, _ = tree.peek_open(peek)
+    atab = tree.anchor_table() if args.reanchor and not args.no_anchor else None
+    asel = tree.peek_anchors(peek) if atab is not None else None
+    chunk = max(8, min(128, len(L) // (4 * threads) or 8))
+    nchunks = (len(L) + chunk - 1) // chunk
+    pc_tab = tree.pseudo_cost_arrays()
+    pc_has = ((pc_tab[2] > 0) | (pc_tab[3] > 0)).astype(np.uint8)
+    cutoff = tree.stats()['primal_bound']
+    deadline = [0.0]
+
+    def work(ci):  # ctypes releases the GIL inside the C oracle: the threads run in parallel
+        if time.perf_counter() > deadline[0]:
+            return 0
+        e0 = min((ci + 1) * chunk, len(L))
+        sl = slice(ci * chunk, e0)
+        if args.dive:  # like the GPU path: node + one child continued on the node's tableau
+            r = O.lp_solve_dive_batch(A, b, c, L[sl], U[sl], V[sl], 1, ints, pc_tab[0], pc_tab[1], pc_has, cutoff,
+                                      anchor_table=atab, anchor_sel=None if asel is None else asel[sl])
+            return e0 - ci * chunk + int((r['dive_var'] >= 0).sum())
+        if atab is not None:  # rule -1: no dive, anchors from the table
+            O.lp_solve_dive_batch(A, b, c, L[sl], U[sl], V[sl], -1, ints, pc_tab[0], pc_tab[1], pc_has, cutoff,
+                                  anchor_table=atab, anchor_sel=asel[sl])
+        else:
+            O.lp_solve_batch(A, b, c, L[sl], U[sl], V[sl])
+        return e0 - ci * chunk
+
+    anchor_cm = contextlib.nullcontext()
+    if not args.no_anchor:  # like the GPU path, warm starts refactor from the root's optimal tableau
+        root = O.lp_solve(A, b, c, l, u)
+        anchor_cm = O.anchored(O.make_anchor(A, b, c, root['vstat']))
+    tc = time.perf_counter()
+    deadline[0] = tc + args.cpu_seconds
+    done, passes = 0, 0
+    with anchor_cm, ThreadPoolExecutor(threads) as ex:
+        while passes == 0 or time.perf_counter() < deadline[0]:   # whole passes until the time is up
+            done += int(sum(ex.map(work, range(nchunks))))
+            passes += 1
+    t_cpu = time.perf_counter() - tc
+    how = 'slack-basis refactorisation' if args.no_anchor else \
+        ('anchored like the GPU path: the tableau of the re-anchored ancestor, read back from the device'
+         if atab is not None else 'anchored at the root tableau like the GPU path')
+    return {'value': done / t_cpu, 'unit': 'node LP-relaxations/s', 'cores': threads, 'kind': 'port',
+            'physical_cores': physical, 'logical_cpus': logical, 'cpus_usable': usable, 'cpu_model': model,
+            'seconds': t_cpu,
+            'sample': f'{done} node LPs in {t_cpu:.1f} s = {passes} pass(es) (the last cut off at the time limit) over '
+                      f'{len(L)} open nodes of the same tree{" and their dive children" if args.dive else ""} (the LPs '
+                      f'the GPU solves next: bounds + warm-start bases read back from the device pool), '
+                      f'oracle/libmipx_oracle.so ({how}), {threads} threads over nodes = every CPU this process may '
+                      f'run on (host: {logical} logical / {physical} physical cores, {model})'}, (L, U, V)
+
+
+def highs_baseline(args, prob, A, b, c, sample):
+    """B2: an independent solver -- scipy's HiGHS dual simplex, one LP per call, one core, cold start
+    (linprog takes no basis), Python call overhead included -- on a slice of the same node LPs, with
+    the objectives cross-checked against the GPU's."""
+    from scipy.optimize import linprog
+    L, U, V = sample
+    k_max = min(len(L), 4096)
+    gpu = prob.solve_batch(L[:k_max], U[:k_max], V[:k_max])
+    t0 = time.perf_counter()
+    k, worst, compared = 0, 0.0, 0
+    while k < k_max and time.perf_counter() - t0 < args.highs_seconds:
+        res = linprog(c, A_ub=-A, b_ub=-b, bounds=np.stack([L[k], U[k]], axis=1), method='highs-ds')
+        if res.status == 0 and gpu['status'][k] == 0:
+            worst = max(worst, abs(res.fun - gpu['obj'][k]) / max(1.0, abs(res.fun)))
+            compared += 1
+        elif res.status == 2:
+            assert gpu['status'][k] == 1, 'HiGHS says infeasible, the engine does not'
+        k += 1
+    el = time.perf_counter() - t0
+    assert worst <= 1e-6, f'HiGHS / engine objective mismatch {worst}'
+    return {'value': k / el, 'unit': 'node LP-relaxations/s', 'cores': 1, 'kind': 'independent solver',
+            'solver': "scipy.optimize.linprog(method='highs-ds')", 'lps': k, 'seconds': el,
+            'max_rel_objective_diff_vs_gpu': worst, 'objectives_compared': compared,
+            'note': 'cold start per LP (no warm-start interface), one core, Python call overhead included; the '
+                    'same node LPs the GPU solved (first %d of the sample)' % k}
+
+
+def time_to_optimal_leg(args, ctx, A, b, c, l, u, ints):
+    """The metric's second leg on its own 256 x 128 instance.  Pure best-first finds no incumbent here
+    in millions of nodes (round 1), the reference's depth-first node class does
+    (nodes/search/depth_first.py:16-28): depth-first in the engine, one-level dive on top."""
+    from simple_mip_solver_amd import _ffi
+    p = _ffi.Problem(ctx, A, b, c)
+    Bt = 1024
+    t = _ffi.Tree(p, ints, l, u, branch_rule='pseudo cost', search_rule='depth first', max_batch=Bt,
+                  pool_capacity=1 << 21)
+    t.set_anchor_mode(True)
+    t.set_dive(True)
+    t0 = time.perf_counter()
+    first, s = None, None
+    while time.perf_counter() - t0 < args.tto_seconds:
+        s = t.solve(mip_gap=1e-4, frontier_batch=Bt, max_steps=2 if first is None else 50)
+        if first is None and s['primal_bound'] < float('inf'):
+            first = {'seconds': time.perf_counter() - t0, 'nodes': s['evaluated_nodes'], 'objective': s['primal_bound']}
+        if s['status'] != 4:
+            break
+    el = time.perf_counter() - t0
+    out = {'instance': f'{len(c)} vars x {len(b)} rows, seed {args.seed} (the metric\'s own instance)',
+           'search': f'PseudoCostBranchDepthFirstSearchNode semantics in the native engine, {Bt} nodes per step + one-level dive',
+           'time_to_first_incumbent': first, 'status': _ffi.TREE_STATUS[s['status']],
+           'seconds': el, 'time_to_optimal': el if s['status'] == 1 else None,
+           'primal_bound': None if s['primal_bound'] == float('inf') else s['primal_bound'],
+           'dual_bound': s['dual_bound'], 'gap': None if s['gap'] < 0 else s['gap'], 'nodes': s['evaluated_nodes'],
+           'note': 'time_to_optimal is null unless the gap closed to 1e-4 inside the time limit'}
+    t.close()
+    p.close()
+    return out
+
+
+def small_time_to_optimal(ctx, dive):
+    """A SMALLER config than the metric's (80 x 40), kept for continuity with round 1: proven optimal."""
+    from simple_mip_solver_amd import _ffi
+    from simple_mip_solver_amd.generators import random_dense_milp_arrays
+    A2, b2, c2, l2, u2, ints2 = random_dense_milp_arrays(80, 40, seed=0)
+    p2 = _ffi.Problem(ctx, A2, b2, c2)
+    best = None
+    for _ in range(3):  # a 25 ms solve: the fastest of three (allocation and first-touch effects)
+        t2 = _ffi.Tree(p2, ints2, l2, u2, branch_rule='pseudo cost', max_batch=4096, pool_capacity=1 << 21)
+        if dive:
+            t2.set_dive(True)
+        tt = time.perf_counter()
+        s2 = t2.solve(mip_gap=1e-4, frontier_batch=4096, max_seconds=30.0)
+        el2 = time.perf_counter() - tt
+        t2.close()
+        if best is None or el2 < best[0]:
+            best = (el2, s2)
+    p2.close()
+    el2, s2 = best
+    return {'instance': '80 vars x 40 rows, seed 0, same generator (a smaller config than the metric\'s)',
+            'seconds': el2, 'status': _ffi.TREE_STATUS[s2['status']], 'objective': s2['primal_bound'],
+            'nodes': s2['evaluated_nodes']}
+
+
+def other_configs(args, ctx):
+    """BASELINE configs C2, C4 and C5 (single GPU), measured in this run after the headline region."""
+    from simple_mip_solver_amd import _ffi
+    from simple_mip_solver_amd.generators import random_dense_milp_arrays
+    out = {}
+    # ---- C2: 1024 independent 64 x 32 roots, cold start, one launch (host buffers: PCIe inclusive)
+    Bn, n2, m2 = 1024, 64, 32
+    P = [random_dense_milp_arrays(n2, m2, seed=k) for k in range(Bn)]
+    A2 = np.stack([p[0] for p in P]); b2 = np.stack([p[1] for p in P]); c2 = np.stack([p[2] for p in P])
+    l2 = np.stack([p[3] for p in P]); u2 = np.stack([p[4] for p in P])
+    best = None
+    for _ in range(3):
+        ctx.sync(); ctx.timer_start()
+        t0 = time.perf_counter()
+        g = _ffi.solve_multi(ctx, A2, b2, c2, l2, u2)
+        wall = time.perf_counter() - t0
+        dev_ms = ctx.timer_stop()
+        if best is None or wall < best[0]:
+            best = (wall, dev_ms, g)
+    wall, dev_ms, g = best
+    piv = int(g['npivots'].sum())
+    byt = algorithmic_bytes(m2, n2, Bn, piv)
+    out['C2'] = {'workload': '1024 independent random dense MILPs, 64 vars x 32 rows, seeds 0..1023, root relaxation, cold '
+                             'start, one launch (mipx_lp_solve_multi; HOST buffers: the PCIe copies are inside)',
+                 'kernel': _ffi.kernel_name(m2, n2), 'lps_per_s': Bn / wall, 'wall_ms': wall * 1e3,
+                 'stream_ms_incl_copies': dev_ms, 'mean_pivots_per_lp': piv / Bn,
+                 'optimal': int((g['status'] == 0).sum()),
+                 'roofline': {'bound': 'hbm', 'model_hbm_GBps': byt / (dev_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS,
+                              'note': 'algorithmic bytes (SURVEY 8d) over the stream time incl. the PCIe copies; the '
+                                      'tableau is register-resident, the launch is bound by the 0.6 MB/LP of copies and '
+                                      'the dependent pivots of one cold LP'}}
+    # ---- C4: the metric's instance with Gomory cut rounds inside the engine
+    n, m = 256, 128
+    A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=args.seed)
+    prob = _ffi.Problem(ctx, A, b, c)
+    B4, steps4 = 4096, 10
+    t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=B4, pool_capacity=2 * B4 * (steps4 + 14),
+                  cut_params=dict(max_abs_coef=1000.0 * float(np.max(np.abs(A))), exact_tableau=0))
+    t.set_anchor_mode(True)
+    st = t.stats()
+    while st['open_nodes'] < B4 or st['evaluated_nodes'] == 0:
+        st = t.solve(mip_gap=0.0, frontier_batch=min(B4, 1024), max_steps=1)
+    b0, c0 = t.stats(), t.cut_stats()
+    ctx.sync()
+    t0 = time.perf_counter()
+    st = t.solve(mip_gap=0.0, frontier_batch=B4, max_steps=steps4)
+    ctx.sync()
+    el = time.perf_counter() - t0
+    c1 = t.cut_stats()
+    d4 = {k: st[k] - b0[k] for k in ('evaluated_nodes', 'lp_solved', 'probes_solved', 'pivots', 'steps')}
+    out['C4'] = {'workload': f'C3\'s instance with gomory_cuts=True (the reference default): every node runs '
+                             f'BaseNode._base_bound\'s cut loop inside the engine, {B4} nodes per step, best-first, anchored, '
+                             f'no dive', 'kernel': _ffi.kernel_name(m, n) + ' (cut-row variant)',
+                 'nodes_per_s': d4['evaluated_nodes'] / el, 'lps_per_s': d4['lp_solved'] / el,
+                 'ms_per_step': el / max(1, d4['steps']) * 1e3, 'steps': d4['steps'],
+                 'mean_pivots_per_lp': d4['pivots'] / max(1, d4['lp_solved']),
+                 'cut_rounds': c1['total_cut_generation_iterations'] - c0['total_cut_generation_iterations'],
+                 'gmic_created': c1['total_number_gmic_created'] - c0['total_number_gmic_created'],
+                 'gmic_added': c1['total_number_gmic_added'] - c0['total_number_gmic_added'],
+                 'gmic_removed': c1['total_number_gmic_removed'] - c0['total_number_gmic_removed'],
+                 'gmic_dropped_for_capacity': c1['dropped'] - c0['dropped'],
+                 'note': 'on this dense family the reference\'s selection rules reject every rounded GMIC (depth >= 0 '
+                         'after the outer rounding): rounds create cuts, add none, and stall after one round'}
+    t.close()
+    prob.close()
+    # ---- C5 on one GPU: 1024 x 512, the HBM-streaming kernel
+    n5, m5, B5, steps5 = 1024, 512, 1024, 5
+    A5, b5, c5, l5, u5, ints5 = random_dense_milp_arrays(n5, m5, seed=0)
+    p5 = _ffi.Problem(ctx, A5, b5, c5)
+    t5 = _ffi.Tree(p5, ints5, l5, u5, branch_rule='pseudo cost', max_batch=B5, pool_capacity=64 * B5)
+    t5.set_anchor_mode(True)
+    t5.set_dive(True)
+    st = t5.stats()
+    while st['open_nodes'] < B5 or st['evaluated_nodes'] == 0:
+        st = t5.solve(mip_gap=0.0, frontier_batch=min(B5, 256), max_steps=1)
+    b0 = t5.stats()
+    ctx.sync()
+    t0 = time.perf_counter()
+    st = t5.solve(mip_gap=0.0, frontier_batch=B5, max_steps=steps5)
+    ctx.sync()
+    el = time.perf_counter() - t0
+    d5 = {k: st[k] - b0[k] for k in ('lp_solved', 'pivots', 'kernel_ms', 'steps', 'dives', 'probes_solved')}
+    ks = d5['kernel_ms'] * 1e-3
+    model = algorithmic_bytes(m5, n5, d5['lp_solved'], d5['pivots'], d5['dives'])
+    real = d5['pivots'] * 2 * 8 * m5 * n5   # what K1b streams: the condensed m x n tableau, read + written per pivot
+    out['C5_single_gpu'] = {
+        'workload': f'1024 vars x 512 rows, seed 0, as C3, {B5} nodes per step + dive children, anchored (one GPU of the '
+                    f'8 the config names)', 'kernel': _ffi.kernel_name(m5, n5),
+        'lps_per_s': d5['lp_solved'] / el, 'kernel_lps_per_s': d5['lp_solved'] / ks, 'ms_per_step': el / max(1, d5['steps']) * 1e3,
+        'mean_pivots_per_lp': d5['pivots'] / max(1, d5['lp_solved']),
+        'roofline': {'bound': 'hbm', 'achieved': real / ks / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                     'frac': real / ks / 1e9 / HBM_PEAK_GBPS, 'model_hbm_GBps': model / ks / 1e9,
+                     'note': 'achieved = bytes the kernel streams per pivot (condensed m x n tableau, read + write) over '
+                             'the K1b launch time (HIP events); model_hbm = SURVEY 8d\'s bordered-tableau figure'}}
+    t5.close()
+    p5.close()
+    return out
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
     # stdout carries the one JSON line and nothing else: libraries that chat on fd 1 (RCCL prints a
     # version banner there) are sent to stderr for the rest of the run
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist, device = None, 'cpu'
-    gpu_index = local_rank
-    if world > 1 or os.environ.get('MIPX_BENCH_FORCE_DIST'):  # the env: RCCL path with one rank
-        import torch
-        import torch.distributed as dist_
-        dist = dist_
-        if os.environ.get('MIPX_BENCH_BACKEND') == 'gloo':
-            # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks: the ranks
-            # share the GPUs that exist and exchange over gloo (never a measurement)
-            gpu_index = local_rank % max(1, _ffi.lib().mipx_device_count())
-            dist.init_process_group('gloo')
-        else:
-            # a launcher may narrow the visible devices per rank: index among those this rank sees
-            gpu_index = local_rank % max(1, torch.cuda.device_count())
-            torch.cuda.set_device(gpu_index)
-            device = torch.device('cuda', gpu_index)
-            dist.init_process_group('nccl', device_id=device)
-            # first collective now: communicator set-up stays out of the timed region
-            warm = torch.zeros(1, dtype=torch.float64, device=device)
-            dist.all_reduce(warm)
-            torch.cuda.synchronize()
+    from simple_mip_solver_amd import _ffi
+    from simple_mip_solver_amd.generators import random_dense_milp_arrays
+    from simple_mip_solver_amd.parallel import env_ranks, global_gap, init_comm
 
+    rank, local_rank, world = env_ranks()
+    gpu_index = local_rank % max(1, _ffi.lib().mipx_device_count())  # (a launcher may narrow the visible devices)
     n, m, B = args.vars, args.cons, args.batch
-    tto_dive = args.dive
     if _ffi.kernel_name(m, n) == 'lp_dual_simplex_big' and '--reanchor' not in sys.argv:
         args.reanchor = 0  # (HBM-streaming kernel: a per-node 4 MB anchor costs more than the pivots it saves at this depth)
     ctx = _ffi.Context(gpu_index)
+    comm, rehearsal = None, False
+    if world > 1 and os.environ.get('MIPX_BENCH_TRANSPORT') == 'gloo':
+        # rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (RCCL refuses two ranks
+        # on one device): the same exchange protocol over the test transport.  Never a measurement.
+        import torch.distributed as dist
+        dist.init_process_group('gloo')
+        from tests.support.gloo_comm import make_comm
+        comm, rehearsal = make_comm(ctx), True
+    elif world > 1:
+        comm = init_comm(ctx, rank, world)
+    elif os.environ.get('MIPX_BENCH_FORCE_COMM'):   # the RCCL path with one rank (rehearsal on a one-GPU box)
+        comm = _ffi.Comm(ctx, 0, 1, unique_id=_ffi.comm_unique_id())
     A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=args.seed)
     prob = _ffi.Problem(ctx, A, b, c)
     tree = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', search_rule='best first',
                      strong_branch_iters=5, max_batch=B,
-                     pool_capacity=(2 + 2 * args.dive) * B * (args.steps + args.warmup + 4) + 4 * B * world)
-
+                     pool_capacity=(2 + 2 * args.dive) * B * (args.steps + args.warmup + 8) + 4 * B * world)
     if not args.no_anchor:
         tree.set_anchor_mode(True)  # warm starts refactor from the root's optimal tableau
     if args.dive:
@@ -123,182 +419,68 @@ def main():
     tree.keep_shard(rank, world)
     if args.reanchor and not args.no_anchor:
         tree.reanchor(tree.stats()['open_nodes'])
-    pex = PipelinedExchange(dist, device, n, n_counters=1)
-    pex.start(*tree.pseudo_cost_arrays())  # identical on every rank after the replicated ramp-up
-
-    def run_steps(k):
-        # inside one call the engine overlaps the host half of step i with the GPU half of i+1
-        return tree.solve(mip_gap=0.0, frontier_batch=B, max_steps=k)
+    if comm is not None:
+        tree.set_comm(comm, args.exchange_every)
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            if device != 'cpu':
-                import torch
-                torch.cuda.synchronize()
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
 
     if args.warmup > 0:
-        st = run_steps(args.warmup)
+        tree.solve(mip_gap=0.0, frontier_batch=B, max_steps=args.warmup)
 
-    # CPU baseline sample: the very node LPs the GPU is about to solve (rank 0 only)
-    cpu = None
+    # CPU baseline sample: the very node LPs the GPU is about to solve (rank 0 only; the others wait
+    # at the barrier below)
+    cpu, sample = None, None
     if rank == 0 and args.cpu_seconds > 0:
-        from oracle import oracle as O
-        from concurrent.futures import ThreadPoolExecutor
-        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-        peek = 4 * B * (3 if threads > 4 else 1)
-        L, U, V, _ = tree.peek_open(peek)
-        # the GPU path's anchors (one per re-anchored ancestor), read back for the CPU port
-        atab = tree.anchor_table() if args.reanchor and not args.no_anchor else None
-        asel = tree.peek_anchors(peek) if atab is not None else None
-        chunk = 128
-        nchunks = (len(L) + chunk - 1) // chunk
-        deadline = time.perf_counter() + args.cpu_seconds
-        done_chunks = []
-
-        pc_tab = tree.pseudo_cost_arrays()
-        pc_has = ((pc_tab[2] > 0) | (pc_tab[3] > 0)).astype(np.uint8)
-        cutoff = tree.stats()['primal_bound']
-
-        def work(ci):  # ctypes releases the GIL inside the C oracle: the threads run in parallel
-            if time.perf_counter() > deadline:
-                return 0
-            e0 = min((ci + 1) * chunk, len(L))
-            if args.dive:  # like the GPU path: node + one child continued on the node's tableau
-                r = O.lp_solve_dive_batch(A, b, c, L[ci * chunk:e0], U[ci * chunk:e0], V[ci * chunk:e0], 1,
-                                          ints, pc_tab[0], pc_tab[1], pc_has, cutoff, anchor_table=atab,
-                                          anchor_sel=None if asel is None else asel[ci * chunk:e0])
-                return e0 - ci * chunk + int((r['dive_var'] >= 0).sum())
-            if atab is not None:  # rule -1: no dive, anchors from the table
-                O.lp_solve_dive_batch(A, b, c, L[ci * chunk:e0], U[ci * chunk:e0], V[ci * chunk:e0], -1,
-                                      ints, pc_tab[0], pc_tab[1], pc_has, cutoff, anchor_table=atab,
-                                      anchor_sel=asel[ci * chunk:e0])
-            else:
-                O.lp_solve_batch(A, b, c, L[ci * chunk:e0], U[ci * chunk:e0], V[ci * chunk:e0])
-            return e0 - ci * chunk
-
-        # like the GPU path, warm starts refactor from the root's optimal tableau when anchoring is on
-        import contextlib
-        anchor_cm = contextlib.nullcontext()
-        if not args.no_anchor:
-            root = O.lp_solve(A, b, c, l, u)
-            anchor_cm = O.anchored(O.make_anchor(A, b, c, root['vstat']))
-        deadline = time.perf_counter() + args.cpu_seconds
-        tc = time.perf_counter()
-        done, passes = 0, 0
-        with anchor_cm, ThreadPoolExecutor(threads) as ex:
-            # whole passes over the peeked nodes until about cpu_seconds x 2 of CPU work is done
-            while passes == 0 or ((time.perf_counter() - tc) * threads < 2 * args.cpu_seconds
-                                  and time.perf_counter() < deadline):
-                done += int(sum(ex.map(work, range(nchunks))))
-                passes += 1
-        t_cpu = time.perf_counter() - tc
-        model = ''
-        try:
-            model = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
-        except Exception:
-            pass
-        cpu = {'value': done / t_cpu, 'unit': 'node LP-relaxations/s', 'cores': threads, 'kind': 'port',
-               'sample': f'{done} node LPs = {passes} pass(es) over {len(L)} open nodes of the same tree{" and their dive children" if args.dive else ""} (the LPs the GPU solves next: bounds + '
-                         f'warm-start bases read back from the device pool), oracle/libmipx_oracle.so '
-                         f'({("anchored like the GPU path: the tableau of the re-anchored ancestor, read back from the device" if atab is not None else "anchored at the root tableau like the GPU path") if not args.no_anchor else "slack-basis refactorisation"}), '
-                         f'{threads} threads over nodes, {t_cpu:.1f} s wall; host: {os.cpu_count()} logical '
-                         f'CPUs, {model}'}
+        cpu, sample = cpu_port_baseline(args, tree, A, b, c, l, u, ints, B)
 
     before = tree.stats()
-    trace = [] if os.environ.get('MIPX_BENCH_TRACE') else None
     barrier()
     t0 = time.perf_counter()
-    def do_exchange():
-        # Runs inside the engine's step loop while the GPU works on the steps already queued.
-        # Pipelined: applies the all-reduce posted at the previous call (incumbent / bound MIN,
-        # pseudo-cost updates SUM) and posts the next one without waiting for it.
-        te = time.perf_counter()
-        s_ = tree.stats()
-        got = pex.step(s_['primal_bound'], s_['dual_bound'], [s_['evaluated_nodes']],
-                       *tree.pseudo_cost_arrays())
-        if got is not None:
-            if got[0] < s_['primal_bound']:
-                tree.set_primal_bound(got[0])
-            tree.set_pseudo_cost_arrays(*got[3])
-        if trace is not None:
-            trace.append((time.perf_counter() - te) * 1e3)
-
-    if dist is not None:
-        tree.set_step_hook(do_exchange, args.exchange_every)
-    st = run_steps(args.steps)
-    tree.set_step_hook(None)
-    if dist is not None:  # apply the exchange still in flight and share what came after it
-        s_ = tree.stats()
-        got = pex.drain(s_['primal_bound'], s_['dual_bound'], [s_['evaluated_nodes']],
-                        *tree.pseudo_cost_arrays())
-        if got[0] < s_['primal_bound']:
-            tree.set_primal_bound(got[0])
-        tree.set_pseudo_cost_arrays(*got[3])
-    tc_ = time.perf_counter()
+    st = tree.solve(mip_gap=0.0, frontier_batch=B, max_steps=args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if trace is not None:
-        sys.stderr.write('[bench rank %d] exchanges (ms): %s; closing barrier %.2f ms\n' % (
-            rank, ', '.join('%.2f' % x for x in trace), (time.perf_counter() - tc_) * 1e3))
     after = tree.stats()
-
-    # time-to-optimal leg of the metric: the 256x128 tree cannot be closed in a bench run, so the
-    # same engine solves a small instance of the same family to proven optimality (rank 0, untimed
-    # with respect to `value`)
-    tto = None
-    if rank == 0:
-        A2, b2, c2, l2, u2, ints2 = random_dense_milp_arrays(80, 40, seed=0)
-        p2 = _ffi.Problem(ctx, A2, b2, c2)
-        best = None
-        for _ in range(3):  # a 25 ms solve: the fastest of three (allocation and first-touch effects)
-            t2 = _ffi.Tree(p2, ints2, l2, u2, branch_rule='pseudo cost', max_batch=4096, pool_capacity=1 << 21)
-            if tto_dive:
-                t2.set_dive(True)
-            tt = time.perf_counter()
-            s2 = t2.solve(mip_gap=1e-4, frontier_batch=4096, max_seconds=30.0)
-            el2 = time.perf_counter() - tt
-            t2.close()
-            if best is None or el2 < best[0]:
-                best = (el2, s2)
-        el2, s2 = best
-        tto = {'instance': '80 vars x 40 rows, seed 0, same generator, PseudoCostBranchNode best-first'
-                           + (' + one-level dive' if tto_dive else ''),
-               'seconds': el2,
-               'status': _ffi.TREE_STATUS[s2['status']], 'objective': s2['primal_bound'],
-               'nodes': s2['evaluated_nodes']}
-        p2.close()
 
     d = {k: after[k] - before[k] for k in ('lp_solved', 'probes_solved', 'pivots', 'evaluated_nodes',
                                            'kernel_ms', 'steps', 'dives')}
-    gp, gd, sums, _ = exchange(dist, device, after['primal_bound'], after['dual_bound'],
-                               [d['lp_solved'], d['probes_solved'], d['pivots'], after['open_nodes'],
-                                after['evaluated_nodes']])
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    mine = np.array([elapsed, d['lp_solved'], d['probes_solved'], d['pivots'], after['open_nodes'],
+                     after['evaluated_nodes'] - ramp['evaluated_nodes'], after['primal_bound'], after['dual_bound'],
+                     d['steps']], dtype=np.float64)
+    allr = comm.allgather(mine) if comm is not None else mine[None]
+    gstats = tree.global_stats()
+    if comm is not None:
+        tree.set_comm(None)
 
     if rank == 0:
-        assert d['steps'] == args.steps, 'frontier ran dry inside the timed region'
-        launch_s = d['kernel_ms'] * 1e-3 / args.steps
-        achieved = algorithmic_bytes(m, n, d['lp_solved'], d['pivots'], d['dives']) / args.steps / launch_s / 1e9
-        traffic = None
+        assert np.all(allr[:, 8] >= args.steps), f'a rank ran fewer than {args.steps} steps: {allr[:, 8]}'
+        elapsed_max = float(allr[:, 0].max())
+        lps_total, probes_total = float(allr[:, 1].sum()), float(allr[:, 2].sum())
+        gp = float(allr[:, 6].min()); gd = float(allr[:, 7].min())
+        launch_s = d['kernel_ms'] * 1e-3 / max(1, d['steps'])
+        model_gbps = algorithmic_bytes(m, n, d['lp_solved'], d['pivots'], d['dives']) / max(1, d['steps']) / launch_s / 1e9
+        flops = 2.0 * m * n * d['pivots'] / max(1, d['steps']) / launch_s / 1e12
+        traffic, pmc_src, issue = None, None, None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+                pj = json.load(open(pmc))
+                traffic, pmc_src, issue = pj.get('hbm_bytes_per_launch'), pj.get('command'), pj.get('issue')
             except Exception:
                 traffic = None
-        gap = global_gap(gp, gd)
+        hbm_gbps = None if traffic is None else traffic / launch_s / 1e9
+        tto = time_to_optimal_leg(args, ctx, A, b, c, l, u, ints) if args.tto_seconds > 0 and (n, m) == (256, 128) else None
+        tto_small = small_time_to_optimal(ctx, args.dive) if args.tto_seconds > 0 else None
+        highs = highs_baseline(args, prob, A, b, c, sample) if (sample is not None and args.highs_seconds > 0) else None
+        others = other_configs(args, ctx) if args.others else None
         out = {
-            'metric': 'node LP-relaxations/s', 'value': sums[0] / elapsed,
+            'metric': 'node LP-relaxations/s', 'value': lps_total / elapsed_max,
             'unit': 'node LP-relaxations/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'warmup': args.warmup, 'ms_per_step': elapsed_max / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
-            'data': 'synthetic',
+            'data': 'synthetic' + (' (REHEARSAL: ranks share GPUs, gloo transport -- not a measurement)' if rehearsal else ''),
             'config': {
                 'workload': f'{ {(256, 128): "C3", (1024, 512): "C5"}.get((n, m), "custom") }: {n} vars x {m} rows random dense MILP (BASELINE.md sec. 4, seed '
                             f'{args.seed}), PseudoCostBranchNode, best-first, strong_branch_iters=5, '
@@ -307,36 +489,49 @@ def main():
                             + (' + one-level dive (each node and, where the rule needs no probes, one child on the same register tableau)' if args.dive else ''),
                 'frontier_batch_per_gpu': B, 'kernel': _ffi.kernel_name(m, n),
                 'anchored_refactorisation': not args.no_anchor, 'reanchored_after_sharding': bool(args.reanchor and not args.no_anchor), 'dive': bool(args.dive),
-                'dive_children_per_step': d['dives'] / args.steps,
+                'dive_children_per_step': d['dives'] / max(1, d['steps']),
                 'mean_pivots_per_lp': d['pivots'] / max(1, d['lp_solved']),
-                'sb_probes_per_s': sums[1] / elapsed,
-                'nodes_evaluated_total': sums[4], 'open_nodes_total': sums[3],
+                'sb_probes_per_s': probes_total / elapsed_max,
+                'nodes_evaluated_total': ramp['evaluated_nodes'] + int(allr[:, 5].sum()),
+                'nodes_evaluated_note': 'the replicated ramp-up counted once + every rank\'s nodes since sharding',
+                'open_nodes_total': int(allr[:, 4].sum()),
                 'ramp_up_nodes': ramp['evaluated_nodes'],
                 'primal_bound': None if gp == float('inf') else gp, 'dual_bound': gd,
-                'gap': gap, 'time_to_optimal': tto,
-                'parallelism': f'open nodes sharded x{world}, per-GPU best-first queue, '
-                               f'allreduce(MIN) incumbent/bound + allreduce(SUM) pseudo-cost updates every '
-                               f'{args.exchange_every} steps, posted inside the step loop and applied one interval later'},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
-                         'launch_ms': launch_s * 1e3,
-                         'vector_f64': {'achieved': 2.0 * m * n * d['pivots'] / args.steps / launch_s / 1e12,
-                                        'peak': F64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                        'frac': 2.0 * m * n * d['pivots'] / args.steps / launch_s / 1e12
-                                                / F64_VECTOR_PEAK_TFLOPS,
-                                        'note': 'rank-1 tableau updates (2mn flop per pivot) against the '
-                                                'v_fma_f64 rate: the kernel is bound by the dependent '
-                                                'selection chains between the updates, not by either roof'},
-                         'note': 'algorithmic bytes of the dense-tableau HBM model (SURVEY 8d) over '
-                                 'the node-LP kernel time (HIP events on its stream), rank 0; the '
-                                 'tableau is register-resident, so real HBM traffic is far below'},
+                'gap': global_gap(gp, gd),
+                'time_to_optimal': tto, 'time_to_optimal_smaller_config': tto_small,
+                'exchanges': gstats['exchanges'], 'nodes_sent_rank0': gstats['nodes_sent'],
+                'nodes_received_rank0': gstats['nodes_received'],
+                'parallelism': f'open nodes sharded x{world}, per-GPU best-first queue; one all-gather per rank every '
+                               f'{args.exchange_every} steps inside libmipx.so (RCCL: ncclAllGather on its own stream, posted '
+                               f'in the step loop and applied one interval later): incumbent value + solution, shard dual '
+                               f'bounds, open counts, stop flags, counters, pseudo-cost samples; node records to a dry rank by '
+                               f'ncclSend/ncclRecv; no scaling curve is claimed until the driver\'s SCALE record exists',
+                'others': others},
+            'roofline': {
+                'bound': 'hbm',
+                # what the kernel really moves: PMC bytes (profiles/, same command) over the live launch time
+                'achieved': hbm_gbps, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                'frac': None if hbm_gbps is None else hbm_gbps / HBM_PEAK_GBPS,
+                'traffic': traffic, 'traffic_source': pmc_src, 'launch_ms': launch_s * 1e3,
+                'model_hbm': {'achieved': model_gbps, 'frac': model_gbps / HBM_PEAK_GBPS, 'unit': 'GB/s',
+                              'note': 'SURVEY 8d\'s dense-tableau HBM model (algorithmic bytes / launch time): the '
+                                      'tableau is register-resident, this traffic does not happen -- not a roofline '
+                                      'fraction, kept for comparison with round 1'},
+                'vector_f64': {'achieved': flops, 'peak': F64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': flops / F64_VECTOR_PEAK_TFLOPS,
+                               'note': 'rank-1 tableau updates (2mn flop per pivot) against the v_fma_f64 rate'},
+                'issue': issue,
+                'note': 'the node-LP kernel (HIP events on its stream, rank 0).  It is bound by neither roof: one '
+                        'workgroup per CU (the 256 KiB tableau fills half its register file), the control wave\'s '
+                        'dependent selections between the rank-1 sweeps'},
             'cpu_baseline': cpu,
+            'cpu_baseline_highs': highs,
         }
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     tree.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == '__main__':

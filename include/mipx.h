@@ -398,8 +398,9 @@ int mipx_comm_barrier(mipx_comm *c);
  *     contract is objective_value and solution, branch_and_bound.py:236-241);
  *   - the merged pseudo-cost table;
  *   - termination, decided identically by all ranks from the same records: every rank idle (no open
- *     node anywhere), the global gap |primal - min dual| / |primal| <= mip_gap, or any rank's limit
- *     (node_limit, max_seconds, max_steps count per rank);
+ *     node anywhere), the global gap |primal - min dual| / |primal| <= mip_gap, any rank's node_limit /
+ *     max_seconds (they count per rank), or every rank done with its max_steps (a per-rank quota: a
+ *     rank that has done its steps waits in the exchange while the others finish theirs);
  *   - migration: a rank that cannot fill a batch gets half the surplus of the fullest rank (node
  *     records move by ncclSend / ncclRecv; not with cut rounds).
  * A rank without open nodes blocks in the exchange until work or the end arrives.  After the solve
@@ -413,7 +414,9 @@ int mipx_tree_set_comm(mipx_tree *t, mipx_comm *c, int every_steps);
  * [2] open nodes (queued + in flight), [3] stop flag, [4..7] evaluated / LPs / probes / pivots since
  * sharding, [8] 1 if the rank holds a solution for [0], [9] exchange number, [10] its frontier batch,
  * [16..16+n) the solution, then 4 n pseudo-cost samples (sum_l, sum_r, times_l, times_r).
- * reason: 0 go on, 1 no open node anywhere, 2 a rank's stop flag, 3 global gap <= mip_gap.
+ * [3] stop flag: 1 a limit that ends the search, 2 the rank's step quota is done.
+ * reason: 0 go on, 1 no open node anywhere, 2 a rank's limit, 3 global gap <= mip_gap, 4 every rank has
+ * done its steps or run dry.
  * moves: n_moves triples (from rank, to rank, node records), in the order they are carried out. */
 typedef struct mipx_exchange_decision {
     double primal, dual, gap;

@@ -1150,14 +1150,18 @@ void x_decide(int W, int n, const double *records, double mip_gap, bool allow_mi
     double best = inf, dual = inf;
     int who = -1;
     int64_t sums[5] = {0, 0, 0, 0, 0};
-    bool any_stop = false;
+    // stop flags: 1 = a limit that ends the search for everybody (node_limit, max_seconds, unbounded,
+    // a full pool); 2 = this rank has done the steps it was asked for (max_steps is a per-rank quota:
+    // the others finish theirs)
+    bool any_stop = false, all_finished = true;
     for (int r = 0; r < W; r++) {
         const double *q = rec(r);
         if (q[0] < best) best = q[0];
         dual = std::fmin(dual, q[1]);
         sums[0] += (int64_t)q[4]; sums[1] += (int64_t)q[5]; sums[2] += (int64_t)q[6]; sums[3] += (int64_t)q[7];
         sums[4] += (int64_t)q[2];
-        any_stop |= q[3] != 0.0;
+        any_stop |= q[3] == 1.0;
+        all_finished &= q[3] == 2.0 || q[2] == 0.0;
     }
     for (int r = 0; r < W && who < 0; r++)
         if (rec(r)[0] == best && rec(r)[8] != 0.0 && best < inf) who = r;
@@ -1170,7 +1174,7 @@ void x_decide(int W, int n, const double *records, double mip_gap, bool allow_mi
     out->primal = best; out->dual = dual; out->gap = gap; out->incumbent_rank = who;
     for (int k = 0; k < 4; k++) out->sums[k] = sums[k];
     out->open_nodes = sums[4];
-    out->reason = sums[4] == 0 ? 1 : any_stop ? 2 : (gap >= 0 && gap <= mip_gap) ? 3 : 0;
+    out->reason = sums[4] == 0 ? 1 : any_stop ? 2 : (gap >= 0 && gap <= mip_gap) ? 3 : all_finished ? 4 : 0;
     out->done = out->reason != 0;
     out->n_moves = 0;
     // migration: a rank that cannot fill a batch gets half the surplus of the fullest rank
@@ -1544,15 +1548,16 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
     // half of step k+1, whose batch is popped before the children of step k exist.
     const bool overlap = t->pipeline && frontier_batch > 1;
     int cur = 0;
-    // this rank's own limits
-    auto limit_now = [&](int64_t inflight) {
-        if (t->unbounded || hook_stop || t->pool_exhausted) return true;
-        if (node_limit > 0 && t->evaluated + inflight >= node_limit) return true;
+    // this rank's own limits: 1 = one that ends the search, 2 = its step quota is done, 0 = none
+    auto limit_kind = [&](int64_t inflight) {
+        if (t->unbounded || hook_stop || t->pool_exhausted) return 1;
+        if (node_limit > 0 && t->evaluated + inflight >= node_limit) return 1;
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (max_seconds > 0 && el > max_seconds) return true;
-        if (max_steps > 0 && steps >= max_steps) return true;
-        return false;
+        if (max_seconds > 0 && el > max_seconds) return 1;
+        if (max_steps > 0 && steps >= max_steps) return 2;
+        return 0;
     };
+    auto limit_now = [&](int64_t inflight) { return limit_kind(inflight) != 0; };
     auto stop_now = [&](int64_t inflight) {
         if (limit_now(inflight)) return true;
         if (t->comm) return t->x_done;   // (the gap is the ranks' joint decision: x_apply)
@@ -1616,7 +1621,7 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
     // Nothing in flight: out of open nodes, or at one of this rank's limits.  The other ranks may
     // still work: wait for them in the exchange (it blocks until every rank has posted), where open
     // nodes may arrive from a fuller rank or the joint decision to stop is taken.
-    t->x_stop_flag = limit_now(0) ? 1 : 0;
+    t->x_stop_flag = limit_kind(0);
     const int xrc = x_tick(t, true);
     if (xrc) return xrc;
     if (t->x_done) break;

@@ -59,7 +59,15 @@ def test_decision_rules():
     recs = np.stack([record(n, primal=-9.0, dual=-9.0005, open_nodes=5, x=[1, 2, 3]), record(n, dual=-9.0008, open_nodes=5)])
     assert _ffi.exchange_decide(recs, n, mip_gap=1e-4)['reason'] == 3
     assert _ffi.exchange_decide(recs, n, mip_gap=1e-5)['reason'] == 0
-    recs[1, 3] = 1.0
+    recs[1, 3] = 2.0                                                       # rank 1 has done its steps: rank 0 goes on
+    assert _ffi.exchange_decide(recs, n, mip_gap=1e-5)['reason'] == 0
+    recs[0, 3] = 2.0                                                       # both have
+    assert _ffi.exchange_decide(recs, n, mip_gap=1e-5)['reason'] == 4
+    recs[0, 3] = 0.0
+    recs[0, 2] = 0                                                         # rank 0 ran dry instead: nobody can feed it
+    assert _ffi.exchange_decide(recs, n, mip_gap=1e-5)['reason'] == 4
+    recs[0, 2] = 5
+    recs[1, 3] = 1.0                                                       # a limit that ends the search
     assert _ffi.exchange_decide(recs, n, mip_gap=1e-5)['reason'] == 2
     recs[:, 2] = 0
     assert _ffi.exchange_decide(recs, n, mip_gap=1e-5)['reason'] == 1     # idle outranks the flag

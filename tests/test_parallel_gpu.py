@@ -145,11 +145,14 @@ WORKER = textwrap.dedent('''
     assert moved[1, 2] > stx['evaluated_nodes']     # the fed rank did evaluate nodes of its own
     assert np.array_equal(t.solution(), comm.allgather(t.solution())[0])
 
-    # --- limits are joint decisions: one rank's step limit stops both -----------------------------
+    # --- limits: max_steps is a per-rank quota (each rank does its own), a node limit ends it for both
     t = tree()
     r2 = shard_and_attach(t, comm, B, exchange_every=2)
-    st = t.solve(mip_gap=0.0, frontier_batch=B, max_steps=[4, 1000][rank])
-    assert st['status'] == 4 and st['steps'] - r2['steps'] <= 12, st
+    st = t.solve(mip_gap=0.0, frontier_batch=B, max_steps=[4, 9][rank])
+    assert st['status'] == 4 and st['steps'] - r2['steps'] == [4, 9][rank], st
+    st = t.solve(mip_gap=0.0, frontier_batch=B, node_limit=[st['evaluated_nodes'] + 2 * B, 10 ** 9][rank])
+    steps_after = comm.allgather(np.array([st['steps'] - r2['steps'], st['status']], float))
+    assert np.all(steps_after[:, 1] == 4) and steps_after[1, 0] <= 9 + 12, steps_after
     t.set_comm(None)
 
     # --- through the driver -----------------------------------------------------------------------
