@@ -1,0 +1,81 @@
+"""Turn the rocprofv3 passes of scripts/profile_bench.sh into the summaries kept under profiles/."""
+import collections, csv, glob, json, os, sys
+O = sys.argv[1]
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = os.environ.get('PROFILE_TAG', 'r02')
+
+
+def by_grid(trace_dir, out):
+    kt = glob.glob(trace_dir + '/*/*kernel_trace.csv')[0]
+    os.system(f'python3 {R}/scripts/summarize_profile.py {kt} > {out}')
+    st = glob.glob(trace_dir + '/*/*kernel_stats.csv')
+    return st[0] if st else None
+
+
+def counter(tag, name, kernel_substr):
+    vals = collections.defaultdict(list)
+    for f in glob.glob(O + f'/{tag}/*/*counter_collection.csv'):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] == name and kernel_substr in r['Kernel_Name']:
+                vals[int(r['Grid_Size'])].append(float(r['Counter_Value']))
+    return vals
+
+
+def steady(vals):
+    g = max(vals, key=lambda k: (len(vals[k]) > 3, k))   # the steady-state frontier batch
+    return g, sum(vals[g]) / len(vals[g])
+
+
+args = open(O + '/args.txt').read().strip()
+st = by_grid(O + '/trace', O + f'/{TAG}_kernel_by_grid.csv')
+if st:
+    os.system(f'cp {st} {O}/{TAG}_kernel_stats.csv')
+fe, wr = counter('fetch', 'FETCH_SIZE', 'lp_dual_simplex<'), counter('write', 'WRITE_SIZE', 'lp_dual_simplex<')
+g, f_kb = steady(fe)
+_, w_kb = steady(wr)
+issue = {}
+for tag in ('sq1', 'sq2'):
+    names = set()
+    for f in glob.glob(O + f'/{tag}/*/*counter_collection.csv'):
+        for r in csv.DictReader(open(f)):
+            names.add(r['Counter_Name'])
+    for nm in sorted(names):
+        v = counter(tag, nm, 'lp_dual_simplex<')
+        if v and g in v:
+            issue[nm] = sum(v[g]) / len(v[g])
+if issue.get('SQ_WAVE_CYCLES'):
+    wc = issue['SQ_WAVE_CYCLES']
+    issue['derived'] = {
+        'valu_insts_per_wave_cycle': issue.get('SQ_INSTS_VALU', 0) / (4.0 * wc),
+        'active_inst_valu_over_wave_cycles': issue.get('SQ_ACTIVE_INST_VALU', 0) / wc,
+        'active_inst_any_over_wave_cycles': issue.get('SQ_ACTIVE_INST_ANY', 0) / wc,
+        'wait_any_over_wave_cycles': issue.get('SQ_WAIT_ANY', 0) / wc,
+        'note': 'per launch of the steady-state node-LP kernel; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count '
+                'quad-cycles summed over waves (MI355X_MICROARCH.md), SQ_INSTS_* count wave-instructions'}
+out = {"command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ groups (separate passes) -- python3 bench.py " + args,
+       "kernel": f"lp_dual_simplex (K1), grid {g} threads per launch (one frontier batch)",
+       "fetch_size_KB_raw": f_kb, "write_size_KB": w_kb,
+       "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM)",
+       "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024, "issue": issue}
+json.dump(out, open(O + '/pmc_latest.json', 'w'), indent=1)
+print(json.dumps(out)[:1500])
+# K1b
+st = by_grid(O + '/k1b_trace', O + f'/{TAG}_k1b_kernel_by_grid.csv')
+if st:
+    os.system(f'cp {st} {O}/{TAG}_k1b_kernel_stats.csv')
+fe, wr = counter('k1b_fetch', 'FETCH_SIZE', 'lp_dual_simplex_big'), counter('k1b_write', 'WRITE_SIZE', 'lp_dual_simplex_big')
+if fe and wr:
+    g, f_kb = steady(fe)
+    _, w_kb = steady(wr)
+    dur = None
+    for r in csv.DictReader(open(O + f'/{TAG}_k1b_kernel_by_grid.csv')):
+        if 'lp_dual_simplex_big' in r['kernel'] and int(r['grid_x']) == g:
+            dur = float(r['avg_us'])
+    k1b = {"command": "rocprofv3 (trace / --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes) -- python3 scripts/c5_tree.py 1024 1",
+           "kernel": f"lp_dual_simplex_big (K1b) at 1024 x 512, grid {g} threads (1024 nodes + dive children per launch)",
+           "fetch_size_KB_raw": f_kb, "write_size_KB": w_kb, "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024,
+           "avg_launch_us": dur,
+           "hbm_GBps": None if not dur else (2 * f_kb + w_kb) * 1024 / (dur * 1e-6) / 1e9}
+    json.dump(k1b, open(O + f'/{TAG}_k1b_pmc.json', 'w'), indent=1)
+    print(json.dumps(k1b))
+print(open(O + f'/{TAG}_kernel_by_grid.csv').read()[:3000])

@@ -1,39 +1,26 @@
 #!/bin/bash
-# Kernel-trace + HBM PMC passes for the bench workload (run on the GPU box through gpurun).
-# Outputs land in gpurun_out/prof/; copy the summaries into profiles/ afterwards.
+# rocprofv3 passes for the bench workload (run on the GPU box through gpurun): kernel trace + stats,
+# HBM bytes (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes), SQ
+# issue counters; then the same for K1b on config C5.  Outputs land in gpurun_out/prof/; the
+# summaries to be judged are copied into profiles/ afterwards (scripts/collect_profiles.py).
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/prof
 rm -rf $O && mkdir -p $O
-ARGS="--steps ${STEPS:-10} --warmup 3 --cpu-seconds 0 ${EXTRA:-}"
+ARGS="--steps ${STEPS:-10} --warmup 3 --cpu-seconds 0 --highs-seconds 0 --tto-seconds 0 --others 0 ${EXTRA:-}"
+echo "$ARGS" > $O/args.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py $ARGS > $O/trace.log 2>&1
+echo trace done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py $ARGS > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py $ARGS > $O/write.log 2>&1
-python3 - <<'PY'
-import csv, glob, os, collections, json
-R = os.environ['GRAFT_REPO_ROOT']; O = R + '/gpurun_out/prof'
-kt = glob.glob(O + '/trace/*/*kernel_trace.csv')[0]
-os.system(f'python3 {R}/scripts/summarize_profile.py {kt} > {O}/kernel_by_grid.csv')
-st = glob.glob(O + '/trace/*/*kernel_stats.csv')
-if st: os.system(f'cp {st[0]} {O}/kernel_stats.csv')
-def per_launch(tag, counter):
-    vals = collections.defaultdict(list)
-    for f in glob.glob(O + f'/{tag}/*/*counter_collection.csv'):
-        for r in csv.DictReader(open(f)):
-            if r['Counter_Name'] == counter and 'lp_dual_simplex' in r['Kernel_Name']:
-                vals[int(r['Grid_Size'])].append(float(r['Counter_Value']))
-    return vals
-fe, wr = per_launch('fetch', 'FETCH_SIZE'), per_launch('write', 'WRITE_SIZE')
-g = max(fe, key=lambda k: (len(fe[k]) > 3, k))      # the steady-state frontier batch
-f_kb = sum(fe[g]) / len(fe[g]); w_kb = sum(wr[g]) / len(wr[g])
-out = {"command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py " + os.environ.get('ARGS', ''),
-       "kernel": f"lp_dual_simplex (K1), grid {g} threads per launch (one frontier batch)",
-       "fetch_size_KB_raw": f_kb, "write_size_KB": w_kb,
-       "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM)",
-       "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024}
-json.dump(out, open(O + '/pmc_latest.json', 'w'), indent=1)
-print(json.dumps(out))
-print(open(O + '/kernel_by_grid.csv').read())
-PY
-tail -1 $O/trace.log
+echo hbm done
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $O/sq1 -- python3 $R/bench.py $ARGS > $O/sq1.log 2>&1 || echo "sq1 failed"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE --output-format csv -d $O/sq2 -- python3 $R/bench.py $ARGS > $O/sq2.log 2>&1 || echo "sq2 failed"
+echo sq done
+# K1b on C5 (1024 x 512): trace + HBM bytes
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/k1b_trace -- python3 $R/scripts/c5_tree.py 1024 1 > $O/k1b_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/k1b_fetch -- python3 $R/scripts/c5_tree.py 1024 1 > $O/k1b_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/k1b_write -- python3 $R/scripts/c5_tree.py 1024 1 > $O/k1b_write.log 2>&1
+echo k1b done
+python3 $R/scripts/collect_profiles.py $O
