@@ -66,8 +66,8 @@ def parse_args():
     ap.add_argument('--tto-seconds', type=float, default=5.0, help='time limit of the time-to-optimal leg (0: skip)')
     ap.add_argument('--others', type=int, default=1, choices=[0, 1], help='1: also measure C2, C4, C5 (config.others)')
     ap.add_argument('--exchange-every', type=int, default=5, help='steps between exchanges (N > 1)')
-    ap.add_argument('--dive', type=int, default=1, choices=[0, 1],
-                    help='1: one-level plunge on the register tableau (mipx_tree_set_dive)')
+    ap.add_argument('--dive', type=int, default=4, choices=range(0, 9),
+                    help='dive children solved in a row on the tableau a node\'s workgroup holds (mipx_tree_set_dive; 0: off)')
     ap.add_argument('--reanchor', type=int, default=1, choices=[0, 1],
                     help='1: after sharding every open node gets an anchor of its own (mipx_tree_reanchor)')
     ap.add_argument('--no-anchor', action='store_true',
@@ -152,7 +152,7 @@ def cpu_port_baseline(args, tree, A, b, c, l, u, ints, B):
         sl = slice(ci * chunk, e0)
         if args.dive:  # like the GPU path: node + one child continued on the node's tableau
             r = O.lp_solve_dive_batch(A, b, c, L[sl], U[sl], V[sl], 1, ints, pc_tab[0], pc_tab[1], pc_has, cutoff,
-                                      anchor_table=atab, anchor_sel=None if asel is None else asel[sl])
+                                      anchor_table=atab, anchor_sel=None if asel is None else asel[sl], depth=args.dive)
             return e0 - ci * chunk + int((r['dive_var'] >= 0).sum())
         if atab is not None:  # rule -1: no dive, anchors from the table
             O.lp_solve_dive_batch(A, b, c, L[sl], U[sl], V[sl], -1, ints, pc_tab[0], pc_tab[1], pc_has, cutoff,
@@ -223,7 +223,7 @@ def time_to_optimal_leg(args, ctx, A, b, c, l, u, ints):
     t = _ffi.Tree(p, ints, l, u, branch_rule='pseudo cost', search_rule='depth first', max_batch=Bt,
                   pool_capacity=1 << 21)
     t.set_anchor_mode(True)
-    t.set_dive(True)
+    t.set_dive(max(1, args.dive))
     t0 = time.perf_counter()
     first, s = None, None
     while time.perf_counter() - t0 < args.tto_seconds:
@@ -408,7 +408,7 @@ def main():
     if not args.no_anchor:
         tree.set_anchor_mode(True)  # warm starts refactor from the root's optimal tableau
     if args.dive:
-        tree.set_dive(True)
+        tree.set_dive(args.dive)
 
     # ---- untimed: replicated ramp-up, then sharding ------------------------------------------
     st = tree.stats()
@@ -486,9 +486,9 @@ def main():
                             f'{args.seed}), PseudoCostBranchNode, best-first, strong_branch_iters=5, '
                             f'gomory_cuts=False, native frontier engine, {B} open nodes per step per GPU'
                             + (', every open node re-anchored after sharding' if args.reanchor and not args.no_anchor else '')
-                            + (' + one-level dive (each node and, where the rule needs no probes, one child on the same register tableau)' if args.dive else ''),
+                            + (f' + in-place dive (each node and, where the rule needs no probes, up to {args.dive} child(ren) in a row on the same register tableau)' if args.dive else ''),
                 'frontier_batch_per_gpu': B, 'kernel': _ffi.kernel_name(m, n),
-                'anchored_refactorisation': not args.no_anchor, 'reanchored_after_sharding': bool(args.reanchor and not args.no_anchor), 'dive': bool(args.dive),
+                'anchored_refactorisation': not args.no_anchor, 'reanchored_after_sharding': bool(args.reanchor and not args.no_anchor), 'dive': args.dive,
                 'dive_children_per_step': d['dives'] / max(1, d['steps']),
                 'mean_pivots_per_lp': d['pivots'] / max(1, d['lp_solved']),
                 'sb_probes_per_s': probes_total / elapsed_max,

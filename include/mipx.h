@@ -78,6 +78,17 @@ int mipx_lp_dive_batch(mipx_problem *p, int batch, const double *l, const double
                        const uint8_t *has_entry, double cutoff, int32_t *status, double *obj,
                        double *x, int8_t *vstat_out, int32_t *iters, int32_t *npivots,
                        int32_t *dive_var, int32_t *dive_dir, double *dive_val);
+/* The same with up to `depth` (1..8) dive children IN A ROW on one tableau -- a plunge: after each
+ * level's LP the rule branches again where it can.  status, obj, x, vstat_out, iters, npivots have
+ * (depth + 1) * batch rows: the nodes, then their first dive children, then the second, ... (status -1
+ * where a level was not reached); dive_var / dive_dir / dive_val depth * batch entries: the decision
+ * taken after level p's LP at [p * batch + node]. */
+int mipx_lp_plunge_batch(mipx_problem *p, int batch, int depth, const double *l, const double *u,
+                         const int8_t *vstat_in, int max_iter, int rule, const int32_t *int_idx,
+                         int n_int, const double *cost_l, const double *cost_r,
+                         const uint8_t *has_entry, double cutoff, int32_t *status, double *obj,
+                         double *x, int8_t *vstat_out, int32_t *iters, int32_t *npivots,
+                         int32_t *dive_var, int32_t *dive_dir, double *dive_val);
 /*
  * Optional: make warm starts refactor from the tableau of the basis `vstat` (n+m Clp codes, e.g.
  * the root's optimal basis) instead of from the slack basis.  The number of refactorisation pivots
@@ -333,12 +344,13 @@ int mipx_tree_reanchor(mipx_tree *t, int64_t max_nodes);
  * a count. */
 int64_t mipx_tree_peek_anchors(mipx_tree *t, int64_t max_nodes, int32_t *anchor);
 int64_t mipx_tree_anchor_table(mipx_tree *t, double *T, double *vec, int32_t *idx);
-/* Throughput option for frontier batches > 1 (register-tile shapes): the workgroup that solved a
- * node branches in place when the rule can decide without probes (see mipx_lp_dive_batch) and
- * solves one child on the tableau it holds; that child is evaluated in the same step (its sibling
- * is queued as usual).  A best-first search with a one-level plunge: same optimum, different node
- * order.  Not available with max_batch = 1 (the reference's exact order). */
-int mipx_tree_set_dive(mipx_tree *t, int on);
+/* Throughput option for frontier batches > 1: the workgroup that solved a node branches in place
+ * when the rule can decide without probes (see mipx_lp_dive_batch) and solves the child on the
+ * tableau it holds -- and that child's child, up to `depth` (0 off, 1..8) in a row (a plunge: see
+ * mipx_lp_plunge_batch); they are evaluated in the same step, their siblings are queued as usual.
+ * A best-first search with a plunge of that depth: same optimum, different node order.  Not
+ * available with max_batch = 1 (the reference's exact order) or with cut rounds. */
+int mipx_tree_set_dive(mipx_tree *t, int depth);
 /* Step hook: `fn(user)` is called on the calling thread every `every_steps` frontier steps of
  * mipx_tree_solve, after the next step's kernels are queued and before the host waits for the
  * current one -- the slot in which a multi-GPU rank runs its incumbent / bound / pseudo-cost

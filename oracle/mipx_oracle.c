@@ -165,6 +165,12 @@ typedef struct {
     double cutoff;
     int32_t *status; double *obj; double *x; int8_t *vstat; int32_t *iters; int32_t *npivots;
     int32_t *dive_var, *dive_dir; double *dive_val;
+    /* multi-level dive: up to `depth` children in a row on the same tableau (0 reads as 1).  Level p
+     * (1-based) writes its outputs level_stride nodes after level p - 1: status / obj / iters / npivots
+     * at [+ (p-1) * level_stride], x at [+ (p-1) * level_stride * n], vstat likewise with n + m; the
+     * branching decision taken after level p's LP goes to dive_var/dir/val[p * level_stride]. */
+    int32_t depth;
+    int64_t level_stride;
 } mipx_dive_t;
 
 static int lp_solve_impl(int m, int n, const double *A, const double *b, const double *c,
@@ -180,8 +186,9 @@ static int lp_solve_impl(int m, int n, const double *A, const double *b, const d
     double *u = (double *)malloc(sizeof(double) * (size_t)n);
     memcpy(l, l_in, sizeof(double) * (size_t)n);
     memcpy(u, u_in, sizeof(double) * (size_t)n);
-    int pass = 0;
-    if (dv && dv->dive_var) *dv->dive_var = -1;
+    int pass = 0;   /* dive level being solved: 0 the node, p its p-th child in a row */
+    if (dv && dv->dive_var)
+        for (int p = 0; p < (dv->depth > 0 ? dv->depth : 1); p++) dv->dive_var[(size_t)p * (size_t)dv->level_stride] = -1;
     tab_t t;
     t.m = m; t.n = n;
     t.T = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1) * n);
@@ -394,7 +401,7 @@ done:
     /* 4. outputs */
     double dive_obj = INFINITY;
     double *dive_x = NULL;
-    if (x_out || obj_out || (dv && pass == 0)) {
+    if (x_out || obj_out || dv) {
         double *x = (double *)malloc(sizeof(double) * (size_t)n);
         for (int j = 0; j < n; j++) {
             int v = t.nvar[j];
@@ -431,7 +438,7 @@ done:
     if (npivots_out) *npivots_out = npiv;
 
     /* 5. dive: K4's rule on x, then one bound of the chosen (basic) variable moves */
-    if (dv && pass == 0 && !g_refactor_only && status == 0 && dive_obj < dv->cutoff) {
+    if (dv && pass < (dv->depth > 0 ? dv->depth : 1) && !g_refactor_only && status == 0 && dive_obj < dv->cutoff) {
         const double *x = dive_x;
         int win = -1, need_probe = 0; double bk = -INFINITY;
         for (int k = 0; k < dv->n_int; k++) {
@@ -454,13 +461,17 @@ done:
             int basic = 0;
             for (int i = 0; i < m; i++) if (t.bvar[i] == var) basic = 1;
             if (basic) {
+                const size_t ls = (size_t)dv->level_stride, lv = (size_t)pass;   /* this decision: level `pass` */
                 if (dir == 0) u[var] = fl; else l[var] = ce;
-                if (dv->dive_var) *dv->dive_var = var;
-                if (dv->dive_dir) *dv->dive_dir = dir;
-                if (dv->dive_val) *dv->dive_val = v;
-                pass = 1;
-                status_out = dv->status; obj_out = dv->obj; x_out = dv->x; vstat_out = dv->vstat;
-                iters_out = dv->iters; npivots_out = dv->npivots;
+                if (dv->dive_var) dv->dive_var[lv * ls] = var;
+                if (dv->dive_dir) dv->dive_dir[lv * ls] = dir;
+                if (dv->dive_val) dv->dive_val[lv * ls] = v;
+                pass++;
+                status_out = dv->status + lv * ls; obj_out = dv->obj ? dv->obj + lv * ls : NULL;
+                x_out = dv->x ? dv->x + lv * ls * (size_t)n : NULL;
+                vstat_out = dv->vstat ? dv->vstat + lv * ls * (size_t)(n + m) : NULL;
+                iters_out = dv->iters ? dv->iters + lv * ls : NULL;
+                npivots_out = dv->npivots ? dv->npivots + lv * ls : NULL;
                 y_out = NULL; dj_out = NULL;
                 npiv = 0;
                 free(dive_x);
@@ -495,8 +506,9 @@ int mipx_oracle_lp_solve_dive(int m, int n, const double *A, const double *b, co
                          vstat_out, iters_out, npivots_out, dv, NULL, NULL, NULL);
 }
 
-/* batch with the dive: every output array has 2 * batch rows (the nodes, then their dive children;
- * the caller presets status[batch..] = -1 and dive_var[] = -1) */
+/* batch with the dive: every output array has (depth + 1) * batch rows (the nodes, then their first
+ * dive children, then the second ... ; the caller presets status[batch..] = -1), dive_var / dir / val
+ * depth * batch entries (the decision after level p at [p * batch + k]) */
 int mipx_oracle_lp_solve_dive_batch(int m, int n, const double *A, const double *b, const double *c,
                                     int batch, const double *l, const double *u,
                                     const int8_t *vstat_in, int max_iter, int rule, int n_int,
@@ -505,7 +517,7 @@ int mipx_oracle_lp_solve_dive_batch(int m, int n, const double *A, const double 
                                     double *obj, double *x, int8_t *vstat_out, int32_t *iters,
                                     int32_t *npivots, int32_t *dive_var, int32_t *dive_dir,
                                     double *dive_val, const double *atab_T, const double *atab_vec,
-                                    const int32_t *atab_idx, const int32_t *anchor_sel) {
+                                    const int32_t *atab_idx, const int32_t *anchor_sel, int depth) {
     /* optional anchor table (mipx_tree_reanchor): node k starts from entry anchor_sel[k], entries
      * m*n / n+3m / 2n+m apart; -1 or no table: the anchor set by mipx_oracle_set_anchor */
     const size_t nv = (size_t)n + m;
@@ -518,6 +530,7 @@ int mipx_oracle_lp_solve_dive_batch(int m, int n, const double *A, const double 
         dv.vstat = vstat_out ? vstat_out + ck * nv : NULL;
         dv.iters = iters ? iters + ck : NULL; dv.npivots = npivots ? npivots + ck : NULL;
         dv.dive_var = dive_var + k; dv.dive_dir = dive_dir + k; dv.dive_val = dive_val + k;
+        dv.depth = depth > 0 ? depth : 1; dv.level_stride = batch;
         int rc = lp_solve_impl(m, n, A, b, c, l + (size_t)k * n, u + (size_t)k * n,
                                vstat_in ? vstat_in + (size_t)k * nv : NULL, max_iter, status + k,
                                obj ? obj + k : NULL, x ? x + (size_t)k * n : NULL, NULL, NULL,

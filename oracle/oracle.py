@@ -71,18 +71,13 @@ def lp_solve_batch(A, b, c, l, u, vstat=None, max_iter=0):
     return dict(status=status, obj=obj, x=x, y=y, vstat=vout, iters=iters, npivots=npiv)
 
 
-class _Dive(C.Structure):
-    _fields_ = [('rule', C.c_int32), ('n_int', C.c_int32), ('int_idx', _i32p), ('cost_l', _dp),
-                ('cost_r', _dp), ('has_entry', C.POINTER(C.c_uint8)), ('cutoff', C.c_double),
-                ('status', _i32p), ('obj', _dp), ('x', _dp), ('vstat', _i8p), ('iters', _i32p),
-                ('npivots', _i32p), ('dive_var', _i32p), ('dive_dir', _i32p), ('dive_val', _dp)]
-
-
 def lp_solve_dive_batch(A, b, c, l, u, vstat, rule, int_idx, cost_l, cost_r, has_entry, cutoff,
-                        max_iter=0, anchor_table=None, anchor_sel=None):
-    """Node LPs with the in-place dive (LpArgs::dive of the GPU kernel): every array of the result
-    has 2 * batch rows -- the nodes, then their dive children (status -1 where none was solved) --
-    plus dive_var (-1: no dive), dive_dir, dive_val per node."""
+                        max_iter=0, anchor_table=None, anchor_sel=None, depth=1):
+    """Node LPs with the in-place dive (LpArgs::dive of the GPU kernel), up to `depth` children in a
+    row on one tableau: every array of the result has (depth + 1) * batch rows -- the nodes, then
+    their first dive children, then the second ... (status -1 where none was solved) -- plus
+    dive_var (-1: no dive), dive_dir, dive_val with depth * batch entries (the decision taken after
+    level p's LP at p * batch + k)."""
     A = np.ascontiguousarray(A, dtype=np.float64)
     m, n = A.shape
     b = np.ascontiguousarray(b, dtype=np.float64).reshape(m)
@@ -95,10 +90,11 @@ def lp_solve_dive_batch(A, b, c, l, u, vstat, rule, int_idx, cost_l, cost_r, has
     ii = np.ascontiguousarray(int_idx, np.int32)
     cl = np.ascontiguousarray(cost_l, np.float64); cr = np.ascontiguousarray(cost_r, np.float64)
     he = np.ascontiguousarray(has_entry, np.uint8)
-    status = np.full(2 * B, -1, np.int32); obj = np.zeros(2 * B); x = np.zeros((2 * B, n))
-    vout = np.zeros((2 * B, n + m), np.int8); iters = np.zeros(2 * B, np.int32)
-    npiv = np.zeros(2 * B, np.int32)
-    dvar = np.full(B, -1, np.int32); ddir = np.zeros(B, np.int32); dval = np.zeros(B)
+    D = int(depth)
+    status = np.full((D + 1) * B, -1, np.int32); obj = np.zeros((D + 1) * B); x = np.zeros(((D + 1) * B, n))
+    vout = np.zeros(((D + 1) * B, n + m), np.int8); iters = np.zeros((D + 1) * B, np.int32)
+    npiv = np.zeros((D + 1) * B, np.int32)
+    dvar = np.full(D * B, -1, np.int32); ddir = np.zeros(D * B, np.int32); dval = np.zeros(D * B)
     rc = lib().mipx_oracle_lp_solve_dive_batch(
         C.c_int(m), C.c_int(n), _p(A, _dp), _p(b, _dp), _p(c, _dp), C.c_int(B), _p(l, _dp), _p(u, _dp),
         _p(vstat, _i8p), C.c_int(int(max_iter)), C.c_int(int(rule)), C.c_int(len(ii)), _p(ii, _i32p),
@@ -108,7 +104,7 @@ def lp_solve_dive_batch(A, b, c, l, u, vstat, rule, int_idx, cost_l, cost_r, has
         None if anchor_table is None else _p(anchor_table[0], _dp),
         None if anchor_table is None else _p(anchor_table[1], _dp),
         None if anchor_table is None else _p(anchor_table[2], _i32p),
-        None if anchor_sel is None else _p(np.ascontiguousarray(anchor_sel, np.int32), _i32p))
+        None if anchor_sel is None else _p(np.ascontiguousarray(anchor_sel, np.int32), _i32p), C.c_int(D))
     assert rc == 0, f'oracle lp_solve_dive_batch failed rc={rc}'
     return dict(status=status, obj=obj, x=x, vstat=vout, iters=iters, npivots=npiv, dive_var=dvar,
                 dive_dir=ddir, dive_val=dval)

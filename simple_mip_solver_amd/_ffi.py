@@ -30,7 +30,7 @@ SYMBOLS = [
     'mipx_tree_create', 'mipx_tree_destroy', 'mipx_tree_solve', 'mipx_tree_get_stats',
     'mipx_tree_solution', 'mipx_tree_set_primal_bound', 'mipx_tree_pseudo_costs', 'mipx_tree_set_pseudo_costs',
     'mipx_tree_set_trace', 'mipx_tree_trace', 'mipx_tree_peek_open', 'mipx_tree_keep_shard',
-    'mipx_tree_set_step_hook', 'mipx_lp_dive_batch', 'mipx_tree_set_dive', 'mipx_tree_reanchor',
+    'mipx_tree_set_step_hook', 'mipx_lp_dive_batch', 'mipx_lp_plunge_batch', 'mipx_tree_set_dive', 'mipx_tree_reanchor',
     'mipx_tree_peek_anchors', 'mipx_tree_anchor_table',
 ]
 
@@ -503,12 +503,15 @@ class Problem:
                     vstat=[vout[k, :n + m + ncut[k]].copy() for k in range(B)])
 
     def dive_batch(self, l, u, vstat, rule, integer_indices, cost_l=None, cost_r=None, has_entry=None,
-                   cutoff=float('inf'), max_iter=0):
-        """Node LPs with the in-place dive (mipx_lp_dive_batch); arrays of 2 * batch rows (nodes,
-        then dive children, status -1 where none) plus dive_var / dive_dir / dive_val per node."""
+                   cutoff=float('inf'), max_iter=0, depth=1):
+        """Node LPs with the in-place dive (mipx_lp_dive_batch; depth > 1: mipx_lp_plunge_batch): arrays
+        of (depth + 1) * batch rows (nodes, then dive children level by level, status -1 where none)
+        plus dive_var / dive_dir / dive_val with depth * batch entries (the decision after level p at
+        p * batch + node)."""
         n, m = self.n, self.m
         l = np.ascontiguousarray(l, dtype=np.float64).reshape(-1, n)
         B = l.shape[0]
+        D = int(depth)
         u = np.ascontiguousarray(u, dtype=np.float64).reshape(B, n)
         if vstat is not None:
             vstat = np.ascontiguousarray(vstat, dtype=np.int8).reshape(B, n + m)
@@ -516,18 +519,19 @@ class Problem:
         cl = None if cost_l is None else np.ascontiguousarray(cost_l, np.float64)
         cr = None if cost_r is None else np.ascontiguousarray(cost_r, np.float64)
         he = None if has_entry is None else np.ascontiguousarray(has_entry, np.uint8)
-        status = np.zeros(2 * B, np.int32); obj = np.zeros(2 * B); x = np.zeros((2 * B, n))
-        vout = np.zeros((2 * B, n + m), np.int8); iters = np.zeros(2 * B, np.int32)
-        npiv = np.zeros(2 * B, np.int32)
-        dvar = np.zeros(B, np.int32); ddir = np.zeros(B, np.int32); dval = np.zeros(B)
+        R = (D + 1) * B
+        status = np.zeros(R, np.int32); obj = np.zeros(R); x = np.zeros((R, n))
+        vout = np.zeros((R, n + m), np.int8); iters = np.zeros(R, np.int32)
+        npiv = np.zeros(R, np.int32)
+        dvar = np.zeros(D * B, np.int32); ddir = np.zeros(D * B, np.int32); dval = np.zeros(D * B)
         L = lib()
-        L.mipx_lp_dive_batch.argtypes = [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int,
-                                         _vp, _vp, _vp, C.c_double] + [_vp] * 9
-        rc = L.mipx_lp_dive_batch(self._h, B, _ptr(l), _ptr(u), _ptr(vstat), int(max_iter), int(rule),
-                                  _ptr(ii), len(ii), _ptr(cl), _ptr(cr), _ptr(he), float(cutoff),
-                                  _ptr(status), _ptr(obj), _ptr(x), _ptr(vout), _ptr(iters), _ptr(npiv),
-                                  _ptr(dvar), _ptr(ddir), _ptr(dval))
-        self.ctx.check(rc, 'mipx_lp_dive_batch')
+        L.mipx_lp_plunge_batch.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int,
+                                           _vp, _vp, _vp, C.c_double] + [_vp] * 9
+        rc = L.mipx_lp_plunge_batch(self._h, B, D, _ptr(l), _ptr(u), _ptr(vstat), int(max_iter), int(rule),
+                                    _ptr(ii), len(ii), _ptr(cl), _ptr(cr), _ptr(he), float(cutoff),
+                                    _ptr(status), _ptr(obj), _ptr(x), _ptr(vout), _ptr(iters), _ptr(npiv),
+                                    _ptr(dvar), _ptr(ddir), _ptr(dval))
+        self.ctx.check(rc, 'mipx_lp_plunge_batch')
         return dict(status=status, obj=obj, x=x, vstat=vout, iters=iters, npivots=npiv, dive_var=dvar,
                     dive_dir=ddir, dive_val=dval)
 
@@ -653,8 +657,9 @@ class Tree:
         return T, vec, idx
 
     def set_dive(self, on=True):
-        """One-level plunge on the register tableau (mipx_tree_set_dive)."""
-        self.problem.ctx.check(lib().mipx_tree_set_dive(self._h, 1 if on else 0), 'mipx_tree_set_dive')
+        """In-place plunge on the tableau a node's workgroup holds (mipx_tree_set_dive): True / 1 one
+        dive child per node, an int up to 8 that many in a row, False / 0 off."""
+        self.problem.ctx.check(lib().mipx_tree_set_dive(self._h, int(on)), 'mipx_tree_set_dive')
 
     def set_step_hook(self, fn, every_steps=1):
         """Call fn() every `every_steps` frontier steps inside solve(), while the GPU works on the

@@ -159,7 +159,9 @@ class BranchAndBound(BaseAlgorithm):
         batched = frontier_batch is not None and frontier_batch > 1
         native_cuts = frontier_batch is not None and kwargs.get('gomory_cuts', True)
         self._anchor = batched if anchor is None else bool(anchor)
-        self._dive = (batched and not native_cuts) if dive is None else bool(dive)
+        # dive: False / 0 off, True / 1 one dive child per node, an int up to 8 that many in a row
+        self._dive = int(batched and not native_cuts) if dive is None else int(dive)
+        assert 0 <= self._dive <= 8, 'dive is a depth between 0 and 8'
         assert not (self._dive and native_cuts), 'dive is not available with gomory_cuts=True'
         assert not (self._dive and not batched), 'dive needs frontier_batch > 1'
         self._pool_capacity = pool_capacity
@@ -301,7 +303,7 @@ class BranchAndBound(BaseAlgorithm):
             if self._anchor:
                 self._native.set_anchor_mode(True)
             if self._dive:
-                self._native.set_dive(True)
+                self._native.set_dive(self._dive)
         st = None
         if self._comm is not None and not self._sharded:
             from simple_mip_solver_amd.parallel import shard_and_attach

@@ -79,6 +79,8 @@ struct LpArgs {
     // dual simplex on the tableau it holds in registers: the child costs its few iterations, not a
     // tableau load and a refactorisation.  The child's outputs go to position node + dive_off of
     // the same output arrays; dive_var[node] (preset to -1 by the caller) says whether it happened.
+    // dive = D > 1: up to D children in a row (a plunge): level p's outputs at node + p * dive_off, the
+    // branching decision taken after level p's LP at dive_var / dir / val[p * dive_off + node].
     int dive = 0, dive_off = 0;
     int rule = 0;                   // 0 most fractional, 1 pseudo cost (K4's rules)
     int n_int = 0;
@@ -763,9 +765,9 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         }
     }
     if (tid == 0) s.seq = 0;
-    if (DIVE && g.dive_preset && tid == 0) {
-        g.status[(size_t)node + (size_t)g.dive_off] = -1;
-        g.dive_var[node] = -1;
+    if (DIVE && g.dive_preset && tid < g.dive) {   // level tid + 1 has no LP, level tid no decision (yet)
+        g.status[(size_t)node + (size_t)(tid + 1) * (size_t)g.dive_off] = -1;
+        g.dive_var[(size_t)tid * (size_t)g.dive_off + node] = -1;
     }
     if (g.zero16 != nullptr && node == 0 && tid < 4) g.zero16[tid] = 0;
     KPROF_SETUP_MARK(9);
@@ -1327,7 +1329,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         objv = uniform_f64(sum);
     }
     __syncthreads();
-    if (!DIVE || !g.dive || pass != 0 || !solve) break;  // (DIVE = false: the pass loop folds away)
+    if (!DIVE || pass >= g.dive || !solve) break;  // (DIVE = false: the pass loop folds away)
 
     // ---- 5. dive: K4's branching rule on the solution in s.key, by the control wave -----------
     if (ctl) {
@@ -1371,9 +1373,10 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                 if (__ballot(mine) != 0ull) {
                     code = dvar;
                     if (lane == 0) {
-                        g.dive_var[node] = dvar;
-                        g.dive_dir[node] = ddir;
-                        g.dive_val[node] = v;
+                        const size_t di = (size_t)pass * (size_t)g.dive_off + node;
+                        g.dive_var[di] = dvar;
+                        g.dive_dir[di] = ddir;
+                        g.dive_val[di] = v;
                     }
                 }
             }
@@ -1384,8 +1387,8 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     }
     if (__builtin_amdgcn_readfirstlane(s.dive_code) < 0) break;
     KPROF_MARK(11);  // outputs of the node + the branching rule
-    pass = 1;
-    onode = (size_t)node + (size_t)g.dive_off;
+    pass++;
+    onode += (size_t)g.dive_off;
     iters = 0;
     npiv = 0;
     }

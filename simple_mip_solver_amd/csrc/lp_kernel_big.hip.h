@@ -104,9 +104,9 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
         const int cap = 100 * (m + n) + 1000;
         const bool ctl = tid < CT;
         // in-place dive (LpArgs::dive, like K1): pass 0 the node, pass 1 one child on the same slab
-        if (g.dive && g.dive_preset && tid == 0) {
-            g.status[(size_t)node + (size_t)g.dive_off] = -1;
-            g.dive_var[node] = -1;
+        if (g.dive && g.dive_preset && tid < g.dive) {
+            g.status[(size_t)node + (size_t)(tid + 1) * (size_t)g.dive_off] = -1;
+            g.dive_var[(size_t)tid * (size_t)g.dive_off + node] = -1;
         }
         if (g.zero16 != nullptr && node == 0 && tid < 4) g.zero16[tid] = 0;
         int pass = 0;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                 if (g.npivots) g.npivots[onode] = npiv;
             }
             // the dive: K4's branching rule on the solution in s_x (wave 0), as in K1
-            if (g.dive && pass == 0) {
+            if (pass < g.dive) {
                 int code = -1, ddir = 0;
                 double dbound = 0.0;
                 const double objv = __shfl(sum, 0, 64);
@@ -511,9 +511,10 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                         if (__any(mine)) {
                             code = dvar;
                             if (lane == 0) {
-                                g.dive_var[node] = dvar;
-                                g.dive_dir[node] = ddir;
-                                g.dive_val[node] = v;
+                                const size_t di = (size_t)pass * (size_t)g.dive_off + node;
+                                g.dive_var[di] = dvar;
+                                g.dive_dir[di] = ddir;
+                                g.dive_val[di] = v;
                                 if (ddir == 0) s_up[dvar] = dbound;
                                 else s_lo[dvar] = dbound;
                             }
@@ -524,10 +525,10 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
             }
         }
         __syncthreads();
-        if (!g.dive || pass != 0) break;
+        if (pass >= g.dive) break;
         if (__builtin_amdgcn_readfirstlane(s_ci[0]) < 0) break;
-        pass = 1;
-        onode = (size_t)node + (size_t)g.dive_off;
+        pass++;
+        onode += (size_t)g.dive_off;
         npiv = 0; iters = 0; degen = 0; status = -1; phase = 2;  // (straight back into the iterations)
         }  // passes
     }

@@ -412,29 +412,41 @@ int mipx_lp_dive_batch(mipx_problem *p, int batch, const double *l, const double
                        const uint8_t *has_entry, double cutoff, int32_t *status, double *obj,
                        double *x, int8_t *vstat_out, int32_t *iters, int32_t *npivots,
                        int32_t *dive_var, int32_t *dive_dir, double *dive_val) {
+    return mipx_lp_plunge_batch(p, batch, 1, l, u, vstat_in, max_iter, rule, int_idx, n_int, cost_l, cost_r,
+                                has_entry, cutoff, status, obj, x, vstat_out, iters, npivots, dive_var, dive_dir,
+                                dive_val);
+}
+
+int mipx_lp_plunge_batch(mipx_problem *p, int batch, int depth, const double *l, const double *u,
+                         const int8_t *vstat_in, int max_iter, int rule, const int32_t *int_idx,
+                         int n_int, const double *cost_l, const double *cost_r,
+                         const uint8_t *has_entry, double cutoff, int32_t *status, double *obj,
+                         double *x, int8_t *vstat_out, int32_t *iters, int32_t *npivots,
+                         int32_t *dive_var, int32_t *dive_dir, double *dive_val) {
     if (!p) return MIPX_EINVAL;
     mipx_ctx *ctx = p->ctx;
-    if (batch < 0 || n_int < 0 || (rule != 0 && rule != 1) ||
+    if (batch < 0 || n_int < 0 || depth < 1 || depth > 8 || (rule != 0 && rule != 1) ||
         (batch > 0 && (!l || !u || !status || !dive_var || !dive_dir || !dive_val)) ||
         (n_int > 0 && (!int_idx || (rule == 1 && (!cost_l || !cost_r || !has_entry)))))
-        return fail(ctx, MIPX_EINVAL, "mipx_lp_dive_batch: bad argument");
+        return fail(ctx, MIPX_EINVAL, "mipx_lp_plunge_batch: bad argument");
     if (batch == 0) return MIPX_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t B = (size_t)batch, n = (size_t)p->n, m = (size_t)p->m, nv = n + m, ni = (size_t)(n_int ? n_int : 1);
+    const size_t LB = ((size_t)depth + 1) * B, DB = (size_t)depth * B;   // output rows, decisions
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_l = carve(B * n * 8), o_u = carve(B * n * 8), o_vin = carve(B * nv),
-                 o_st = carve(2 * B * 4), o_obj = carve(2 * B * 8), o_x = carve(2 * B * n * 8),
-                 o_vout = carve(2 * B * nv), o_it = carve(2 * B * 4), o_np = carve(2 * B * 4),
-                 o_dv = carve(B * 4), o_dd = carve(B * 4), o_dx = carve(B * 8), o_ii = carve(ni * 4),
+                 o_st = carve(LB * 4), o_obj = carve(LB * 8), o_x = carve(LB * n * 8),
+                 o_vout = carve(LB * nv), o_it = carve(LB * 4), o_np = carve(LB * 4),
+                 o_dv = carve(DB * 4), o_dd = carve(DB * 4), o_dx = carve(DB * 8), o_ii = carve(ni * 4),
                  o_cl = carve(n * 8), o_cr = carve(n * 8), o_he = carve(n);
     char *base = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&base, off));
     hipStream_t st = ctx->stream;
     auto run = [&]() -> int {
         HIP_TRY(ctx, hipMemsetAsync(base, 0, off, st));
-        HIP_TRY(ctx, hipMemsetAsync(base + o_st + B * 4, 0xff, B * 4, st));  // no child: status -1
-        HIP_TRY(ctx, hipMemsetAsync(base + o_dv, 0xff, B * 4, st));           // no dive: -1
+        HIP_TRY(ctx, hipMemsetAsync(base + o_st + B * 4, 0xff, DB * 4, st));  // no child: status -1
+        HIP_TRY(ctx, hipMemsetAsync(base + o_dv, 0xff, DB * 4, st));          // no dive: -1
         HIP_TRY(ctx, hipMemcpyAsync(base + o_l, l, B * n * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(base + o_u, u, B * n * 8, hipMemcpyHostToDevice, st));
         if (vstat_in) HIP_TRY(ctx, hipMemcpyAsync(base + o_vin, vstat_in, B * nv, hipMemcpyHostToDevice, st));
@@ -457,7 +469,7 @@ int mipx_lp_dive_batch(mipx_problem *p, int batch, const double *l, const double
         a.y = nullptr; a.vstat_out = (int8_t *)(base + o_vout);
         a.iters = (int32_t *)(base + o_it); a.npivots = (int32_t *)(base + o_np); a.batch = batch;
         a.dbg_T = nullptr; a.dbg_vec = nullptr; a.dbg_idx = nullptr; a.dbg_all = 0;
-        a.dive = 1; a.dive_off = batch; a.rule = rule; a.n_int = n_int;
+        a.dive = depth; a.dive_off = batch; a.rule = rule; a.n_int = n_int;
         a.int_idx = (const int32_t *)(base + o_ii);
         a.cost_l = (const double *)(base + o_cl); a.cost_r = (const double *)(base + o_cr);
         a.has_entry = (const uint8_t *)(base + o_he);
@@ -466,15 +478,15 @@ int mipx_lp_dive_batch(mipx_problem *p, int batch, const double *l, const double
         a.dive_val = (double *)(base + o_dx);
         const int rc = launch_lp_any(p, a, batch);
         if (rc) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(status, base + o_st, 2 * B * 4, hipMemcpyDeviceToHost, st));
-        if (obj) HIP_TRY(ctx, hipMemcpyAsync(obj, base + o_obj, 2 * B * 8, hipMemcpyDeviceToHost, st));
-        if (x) HIP_TRY(ctx, hipMemcpyAsync(x, base + o_x, 2 * B * n * 8, hipMemcpyDeviceToHost, st));
-        if (vstat_out) HIP_TRY(ctx, hipMemcpyAsync(vstat_out, base + o_vout, 2 * B * nv, hipMemcpyDeviceToHost, st));
-        if (iters) HIP_TRY(ctx, hipMemcpyAsync(iters, base + o_it, 2 * B * 4, hipMemcpyDeviceToHost, st));
-        if (npivots) HIP_TRY(ctx, hipMemcpyAsync(npivots, base + o_np, 2 * B * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(dive_var, base + o_dv, B * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(dive_dir, base + o_dd, B * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(dive_val, base + o_dx, B * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(status, base + o_st, LB * 4, hipMemcpyDeviceToHost, st));
+        if (obj) HIP_TRY(ctx, hipMemcpyAsync(obj, base + o_obj, LB * 8, hipMemcpyDeviceToHost, st));
+        if (x) HIP_TRY(ctx, hipMemcpyAsync(x, base + o_x, LB * n * 8, hipMemcpyDeviceToHost, st));
+        if (vstat_out) HIP_TRY(ctx, hipMemcpyAsync(vstat_out, base + o_vout, LB * nv, hipMemcpyDeviceToHost, st));
+        if (iters) HIP_TRY(ctx, hipMemcpyAsync(iters, base + o_it, LB * 4, hipMemcpyDeviceToHost, st));
+        if (npivots) HIP_TRY(ctx, hipMemcpyAsync(npivots, base + o_np, LB * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dive_var, base + o_dv, DB * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dive_dir, base + o_dd, DB * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dive_val, base + o_dx, DB * 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         return MIPX_OK;
     };

@@ -201,8 +201,12 @@ struct StepBuf {
     hipEvent_t e0 = nullptr, e1 = nullptr, done = nullptr;
     std::vector<int64_t> ids;
     std::vector<NodeRec> recs;  // the batch's node records, copied at pop time (one random access per node and step)
-    std::vector<int32_t> slots, br_pos, br_slot, br_var, br_child;  // staging kept alive
-    std::vector<int32_t> br2_pos, br2_slot, br2_var, br2_child, dive_slots;  // children of the dive children
+    std::vector<int32_t> slots;  // staging kept alive
+    // branching parents by dive level (0: the batch, p: the p-th dive children): output position,
+    // record row, variable, and the two child rows each
+    struct Branchings { std::vector<int32_t> pos, slot, var, child; };
+    std::vector<Branchings> br;
+    std::vector<int32_t> dive_slots;  // record rows of the dive children (freed with the step)
     // cut rounds (mipx_tree_create_ex with cut parameters): per node of the batch the working cut
     // list, the row duals, the loop's state and the pool of candidate cuts (a slab of slab_rows rows)
     int32_t *w_ncut = nullptr, *w_ids = nullptr, *cs_state = nullptr, *cs_active = nullptr,
@@ -211,7 +215,7 @@ struct StepBuf {
     double *d_y = nullptr, *cs_before = nullptr, *slab_pi = nullptr, *slab_pi0 = nullptr,
            *dump_T = nullptr, *dump_vec = nullptr;
     int32_t *h_cs = nullptr;   // pinned: [counters (4) | state fields 0..6 + w_ncut (8 x max_batch)]
-    bool dive = false;  // this step was launched with the in-place dive
+    int dive = 0;  // this step was launched with the in-place dive: children in a row per node
     bool scored_once = false;  // K4 ran on this step (the first run's request counter was zeroed by K1)
     int B = 0;
     bool in_flight = false;
@@ -242,7 +246,7 @@ struct mipx_tree {
     char *h_pres = nullptr;     // pinned mirror of the probe results [pp_obj | pp_status]
     StepBuf buf[2];
     bool table_dirty = false, pipeline = true;
-    bool dive = false;      // mipx_tree_set_dive
+    int dive = 0;           // mipx_tree_set_dive: dive children in a row per node (0: off)
     bool pool_exhausted = false;
     int64_t age_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // popped nodes by age in steps (1 = created by the previous step)
     int64_t depth_sum = 0;
@@ -382,8 +386,8 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
               int8_t *vout, int32_t *iters, int32_t *npiv, hipStream_t stream = nullptr,
               const StepBuf *dive = nullptr, const int32_t *asel = nullptr, const CutLaunch *cl = nullptr) {
     mipx::LpArgs a;
-    if (dive) {  // in-place dive: K4's rule inside K1, children at positions batch .. 2 * batch - 1
-        a.dive = 1; a.dive_off = batch; a.rule = t->rule; a.n_int = t->n_int;
+    if (dive) {  // in-place dive: K4's rule inside K1, level p's children at positions p * batch ..
+        a.dive = dive->dive; a.dive_off = batch; a.rule = t->rule; a.n_int = t->n_int;
         a.int_idx = t->d_int_idx; a.cost_l = t->d_cost_l; a.cost_r = t->d_cost_r; a.has_entry = t->d_has;
         a.dive_cutoff = t->primal;
         a.dive_var = dive->d_dvar; a.dive_dir = dive->d_ddir; a.dive_val = dive->d_dval;
@@ -428,6 +432,24 @@ int tree_d2h(mipx_tree *t, void *dst, const void *src, size_t bytes) {
 }
 
 constexpr int kAskCap = 2048;  // probe requests per step carried in the packed read-back
+constexpr int kMaxDive = 8;    // dive children in a row per node (buffers are sized for it)
+
+// What the host reads back every step, packed so that ONE copy into pinned memory fetches it, laid
+// out for L = 1 + dive output levels of max_batch positions each:
+//   [obj | bval] (L * MB f64 each) [dive_val] ((L - 1 or 1) * MB f64)
+//   [status | bidx | mipf | nprobe | npiv] (L * MB i32 each) [dive_var | dive_dir] ((L - 1 or 1) * MB each)
+//   then the probe requests
+void layout_pack(mipx_tree *t, StepBuf &S, int levels) {
+    const size_t MB = (size_t)t->max_batch, OB = (size_t)levels * MB, DB = (size_t)(levels > 1 ? levels - 1 : 1) * MB;
+    S.d_obj = (double *)S.d_pack; S.d_bval = S.d_obj + OB; S.d_dval = S.d_bval + OB;
+    S.d_status = (int32_t *)(S.d_dval + DB); S.d_bidx = S.d_status + OB; S.d_mipf = S.d_bidx + OB;
+    S.d_nprobe = S.d_mipf + OB; S.d_npiv = S.d_nprobe + OB;
+    S.d_dvar = S.d_npiv + OB; S.d_ddir = S.d_dvar + DB;
+    S.ask_off = (OB * (2 * 8 + 5 * 4) + DB * (8 + 2 * 4) + 15) / 16 * 16;
+    S.pack_bytes = S.ask_off + 16 + (size_t)kAskCap * sizeof(mipx::ScoreArgs::Ask);
+    S.d_ask_count = (int32_t *)((char *)S.d_pack + S.ask_off);
+    S.d_ask = (mipx::ScoreArgs::Ask *)((char *)S.d_pack + S.ask_off + 16);
+}
 
 int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false, bool no_ask = false) {
     mipx::ScoreArgs s;
@@ -440,7 +462,7 @@ int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false, bool no
     s.probe_list = S.d_plist;
     s.ask_count = S.d_ask_count; s.ask_cap = kAskCap; s.ask = (side || no_ask) ? nullptr : S.d_ask;
     s.ask_nodes = S.B;  // dive children (positions >= B) are never probed in their own step
-    if (!side && !no_ask && !(S.dive && batch == 2 * S.B && !S.scored_once))
+    if (!side && !no_ask && !(S.dive && batch == (S.dive + 1) * S.B && !S.scored_once))
         HIP_TRY(t->ctx, hipMemsetAsync(S.d_ask_count, 0, 16, t->ctx->stream));
     if (!no_ask) S.scored_once = true;
     hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, side ? t->st2 : t->ctx->stream, s);
@@ -562,7 +584,7 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
                    S.d_x, S.d_vout, S.d_iters, S.d_npiv, nullptr, S.dive ? &S : nullptr, S.d_slot + B);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(S.e1, st));
-    if ((rc = launch_score(t, S, S.dive ? 2 * B : B))) return rc;
+    if ((rc = launch_score(t, S, (S.dive + 1) * B))) return rc;
     HIP_TRY(ctx, hipEventRecord(S.done, st));
     return MIPX_OK;
 }
@@ -712,14 +734,18 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     }
     // one copy (pinned destination) for everything the host reads per node
     if ((rc = tree_d2h(t, S.h_pack, S.d_pack, S.pack_bytes))) return rc;
-    const size_t MB = (size_t)t->max_batch, OB = 2 * MB;
+    const int L = t->dive + 1;   // (the pack is laid out for the tree's dive depth: layout_pack)
+    const size_t MB = (size_t)t->max_batch, OB = (size_t)L * MB, DB = (size_t)(L > 1 ? L - 1 : 1) * MB;
     double *obj = (double *)S.h_pack, *bval = obj + OB, *dval = bval + OB;
-    int32_t *status = (int32_t *)(dval + MB), *bidx = status + OB, *mipf = bidx + OB, *nprobe = mipf + OB,
-            *npiv = nprobe + OB, *dvar = npiv + OB, *ddir = dvar + MB;
-    const int NB = S.dive ? 2 * B : B;  // output positions in use: the batch, then its dive children
-    // a dive child counts when its LP was solved in place and it needs no strong-branching
-    // initialisation of its own (else it is dropped and queued like any other child)
-    auto dived = [&](int k) { return S.dive && dvar[k] >= 0 && status[B + k] >= 0 && nprobe[B + k] == 0; };
+    int32_t *status = (int32_t *)(dval + DB), *bidx = status + OB, *mipf = bidx + OB, *nprobe = mipf + OB,
+            *npiv = nprobe + OB, *dvar = npiv + OB, *ddir = dvar + DB;
+    const int NB = (S.dive + 1) * B;  // output positions in use: the batch, then its dive children level by level
+    // The node at position pos (level pos / B) was followed in place by a dive child at pos + B: it
+    // counts when its LP was solved and it needs no strong-branching initialisation of its own (else
+    // it is dropped and queued like any other child).  The decision taken after pos is dvar[pos].
+    auto dived = [&](int pos) {
+        return pos < S.dive * B && dvar[pos] >= 0 && status[pos + B] >= 0 && nprobe[pos + B] == 0;
+    };
     t->lps += B;
     for (int k = 0; k < B; k++) t->pivots += npiv[k];
     t->phase_ms[1] += ms_since(tp); tp = now();
@@ -845,10 +871,13 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
                 // the dive child: the update for the branch that made it -- like any node only if its
                 // own LP is feasible (pseudo_cost.py:42-43), and only where step 4 will accept the
                 // dive (the reference never creates that child under a pruned or integral parent)
-                const bool child_feasible = S.dive && (status[B + k] == 0 || status[B + k] == 2);
-                if (dived(k) && child_feasible && obj[k] < t->primal && !mipf[k]) {
-                    const double vc = ddir[k] == 0 ? dval[k] - std::floor(dval[k]) : std::ceil(dval[k]) - dval[k];
-                    pc_update(t, dvar[k], ddir[k], status[B + k], obj[B + k], obj[k], vc);
+                // (a plunge: level by level, each child under the node before it)
+                for (int pos = k; dived(pos) && obj[pos] < t->primal && !mipf[pos] &&
+                                  (status[pos] == 0 || status[pos] == 2); pos += B) {
+                    const int cp = pos + B;
+                    if (!(status[cp] == 0 || status[cp] == 2)) break;
+                    const double vc = ddir[pos] == 0 ? dval[pos] - std::floor(dval[pos]) : std::ceil(dval[pos]) - dval[pos];
+                    pc_update(t, dvar[pos], ddir[pos], status[cp], obj[cp], obj[pos], vc);
                     changed = true;
                 }
             } else {
@@ -877,11 +906,10 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     t->phase_ms[2] += ms_since(tp); tp = now();
     // 4. the reference's _evaluate_node bookkeeping, node by node (a dive child right after its
     //    parent: it was solved in the same workgroup)
-    std::vector<int32_t> &br_pos = S.br_pos, &br_slot = S.br_slot, &br_var = S.br_var, &br_child = S.br_child;
-    std::vector<int32_t> &br2_pos = S.br2_pos, &br2_slot = S.br2_slot, &br2_var = S.br2_var,
-                         &br2_child = S.br2_child, &dive_slots = S.dive_slots;
-    br_pos.clear(); br_slot.clear(); br_var.clear(); br_child.clear();
-    br2_pos.clear(); br2_slot.clear(); br2_var.clear(); br2_child.clear(); dive_slots.clear();
+    std::vector<int32_t> &dive_slots = S.dive_slots;
+    if ((int)S.br.size() < L) S.br.resize((size_t)L);
+    for (auto &bl : S.br) { bl.pos.clear(); bl.slot.clear(); bl.var.clear(); bl.child.clear(); }
+    dive_slots.clear();
     int incumbent_pos = -1;
     // One evaluated node at output position pos.  level 0: a node of the batch (pool row
     // `slot`); level 1: a dive child.  Returns the id of the child that was solved in place by
@@ -894,7 +922,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         int64_t dive_child = -1;
         double leaf_value = lp_feasible ? obj[pos] : inf;
         if (lp_feasible && obj[pos] < t->primal) {
-            const bool take_dive = level == 0 && dived(pos);
+            const bool take_dive = dived(pos);
             const int bvar = take_dive ? dvar[pos] : bidx[pos];  // a dive has already branched
             if (mipf[pos]) {
                 t->primal = obj[pos];
@@ -917,7 +945,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
                     c.ncut = t->cuts ? S.h_cs[4 + 7 * MB + pos] : 0;   // the rows of its parent, cuts included
                     c.slot = t->free_slots.back();
                     t->free_slots.pop_back();
-                    (level == 0 ? br_child : br2_child).push_back(c.slot);
+                    S.br[(size_t)level].child.push_back(c.slot);
                     t->nodes.push_back(c);
                     const int64_t cid = (int64_t)t->nodes.size() - 1;
                     if (take_dive && dir == ddir[pos]) {
@@ -926,9 +954,9 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
                         tree_push(t, cid);
                     }
                 }
-                (level == 0 ? br_pos : br2_pos).push_back(pos);
-                (level == 0 ? br_slot : br2_slot).push_back(slot);
-                (level == 0 ? br_var : br2_var).push_back(branched_on);
+                S.br[(size_t)level].pos.push_back(pos);
+                S.br[(size_t)level].slot.push_back(slot);
+                S.br[(size_t)level].var.push_back(branched_on);
                 leaf_value = inf;  // no longer a leaf
             }
         }
@@ -941,17 +969,19 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     };
     for (int k = 0; k < B; k++) {
         int err = MIPX_OK;
-        const int64_t cid = evaluate(ids[k], k, slots[k], 0, S.recs[k].depth, S.recs[k].anchor, err);
+        int64_t cid = evaluate(ids[k], k, slots[k], 0, S.recs[k].depth, S.recs[k].anchor, err);
         if (err) return err;
-        if (cid >= 0) {
+        for (int level = 1; cid >= 0; level++) {   // the plunge: every dive child right after its parent
             const int32_t cslot = t->nodes[cid].slot;
+            const int pos = level * B + k;
             t->lps++;
             t->dives++;
-            t->pivots += npiv[B + k];
-            evaluate(cid, B + k, cslot, 1, S.recs[k].depth + 1, S.recs[k].anchor, err);
+            t->pivots += npiv[pos];
+            const int64_t next = evaluate(cid, pos, cslot, level, S.recs[k].depth + level, S.recs[k].anchor, err);
             if (err) return err;
             dive_slots.push_back(cslot);  // its record row feeds its own children below
             t->nodes[cid].slot = -1;
+            cid = next;
         }
     }
     if (incumbent_pos >= 0) {
@@ -971,7 +1001,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         t->anchor_set = true;
     }
     // 5. children records on the device, then release the evaluated nodes' rows
-    const int P = (int)br_pos.size(), P2 = (int)br2_pos.size();
+    const int P = (int)S.br[0].pos.size();
     if (P > 0) {
         // when steps overlap this runs on its own stream, beside the node LPs of the step in flight
         // (it writes fresh pool rows only); the next launch waits for it
@@ -1000,11 +1030,15 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             HIP_TRY(ctx, hipGetLastError());
             return MIPX_OK;
         };
-        const size_t half = 5 * (size_t)t->max_batch;  // second half of the staging: dive children's children
-        if ((rc = children(P, br_slot, br_pos, br_var, br_child, t->h_pairs, t->d_pairs))) return rc;
-        // (same stream: the records of the dive children exist before their children are derived)
-        if (P2 > 0 && (rc = children(P2, br2_slot, br2_pos, br2_var, br2_child, t->h_pairs + half, t->d_pairs + half)))
-            return rc;
+        // level by level on one stream: the record of a dive child exists before its children are derived
+        const size_t part = 5 * (size_t)t->max_batch;  // staging per level
+        for (int level = 0; level < L; level++) {
+            const auto &bl = S.br[(size_t)level];
+            if (bl.pos.empty()) break;   // (no branching at this level: none below it either)
+            if ((rc = children((int)bl.pos.size(), bl.slot, bl.pos, bl.var, bl.child, t->h_pairs + (size_t)level * part,
+                               t->d_pairs + (size_t)level * part)))
+                return rc;
+        }
         if (overlapped) {
             HIP_TRY(ctx, hipEventRecord(t->ev_child, t->st3));
             t->child_pending = true;
@@ -1354,8 +1388,9 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
     rc |= dmalloc(ctx, &t->pool_l, cap * n); rc |= dmalloc(ctx, &t->pool_u, cap * n);
     rc |= dmalloc(ctx, &t->pool_v, cap * nv);
     rc |= dmalloc(ctx, &t->d_int_idx, (size_t)n_int);
-    rc |= dmalloc(ctx, &t->d_pairs, 5 * (pc / 2 > 2 * B ? pc / 2 : 2 * B));   // (second half: children of dive children)
-    rc |= dmalloc(ctx, &t->d_pairs2, 5 * (pc / 2 > 2 * B ? pc / 2 : 2 * B));
+    const size_t LC = (size_t)kMaxDive + 1;   // output levels the buffers are sized for
+    rc |= dmalloc(ctx, &t->d_pairs, 5 * (pc / 2 > LC * B ? pc / 2 : LC * B));   // (one part per dive level)
+    rc |= dmalloc(ctx, &t->d_pairs2, 5 * (pc / 2 > LC * B ? pc / 2 : LC * B));
     rc |= dmalloc(ctx, &t->d_cost_l2, n); rc |= dmalloc(ctx, &t->d_cost_r2, n); rc |= dmalloc(ctx, &t->d_has2, n);
     // The side streams carry short, latency-critical work (probes, re-scoring, child records) that
     // must overtake the 2 ms node-LP launch queued on the main stream.  HIP multiplexes the streams
@@ -1367,7 +1402,7 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
     if (hipStreamCreateWithPriority(&t->st2, hipStreamNonBlocking, prio_greatest) != hipSuccess) rc |= MIPX_EHIP;
     if (hipStreamCreateWithPriority(&t->st3, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&t->ev_child, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc((void **)&t->h_pairs, 10 * B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
+        hipHostMalloc((void **)&t->h_pairs, 5 * ((size_t)kMaxDive + 1) * B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
     if (t->cuts) {
         const size_t M = (size_t)t->mrows, K = (size_t)t->kc, SR = (size_t)t->slab_rows;
         rc |= dmalloc(ctx, &t->store_pi, (size_t)t->store_cap * n); rc |= dmalloc(ctx, &t->store_pi0, (size_t)t->store_cap);
@@ -1392,24 +1427,18 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
     }
     for (StepBuf &S : t->buf) {
         rc |= dmalloc(ctx, &S.d_slot, 2 * B);   // [pool rows | anchor-table entries] of the batch
-        // per-node outputs have 2 * B rows: the batch, then its dive children
-        rc |= dmalloc(ctx, &S.d_iters, 2 * B);
-        S.ask_off = (2 * B * (2 * 8 + 5 * 4) + B * (8 + 2 * 4) + 15) / 16 * 16;
-        S.pack_bytes = S.ask_off + 16 + (size_t)kAskCap * sizeof(mipx::ScoreArgs::Ask);
-        rc |= dmalloc(ctx, &S.d_pack, S.pack_bytes);
-        if (hipHostMalloc((void **)&S.h_pack, S.pack_bytes, hipHostMallocDefault) != hipSuccess ||
+        // per-node outputs have one row per output level: the batch, then its dive children level by
+        // level (allocated for the deepest plunge, laid out for the depth in use: layout_pack)
+        rc |= dmalloc(ctx, &S.d_iters, LC * B);
+        const size_t pack_cap = (LC * B * (2 * 8 + 5 * 4) + LC * B * (8 + 2 * 4) + 15) / 16 * 16 + 16 +
+                                (size_t)kAskCap * sizeof(mipx::ScoreArgs::Ask);
+        rc |= dmalloc(ctx, &S.d_pack, pack_cap);
+        if (hipHostMalloc((void **)&S.h_pack, pack_cap, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc((void **)&S.h_slot, 2 * B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
-        if (S.d_pack) {
-            S.d_obj = (double *)S.d_pack; S.d_bval = S.d_obj + 2 * B; S.d_dval = S.d_bval + 2 * B;
-            S.d_status = (int32_t *)(S.d_dval + B); S.d_bidx = S.d_status + 2 * B; S.d_mipf = S.d_bidx + 2 * B;
-            S.d_nprobe = S.d_mipf + 2 * B; S.d_npiv = S.d_nprobe + 2 * B;
-            S.d_dvar = S.d_npiv + 2 * B; S.d_ddir = S.d_dvar + B;
-            S.d_ask_count = (int32_t *)((char *)S.d_pack + S.ask_off);
-            S.d_ask = (mipx::ScoreArgs::Ask *)((char *)S.d_pack + S.ask_off + 16);
-        }
-        rc |= dmalloc(ctx, &S.d_plist, 2 * B * (size_t)(n_int ? n_int : 1));
-        rc |= dmalloc(ctx, &S.d_x, 2 * B * n);
-        rc |= dmalloc(ctx, &S.d_vout, 2 * B * nv);
+        if (S.d_pack) layout_pack(t, S, 1);
+        rc |= dmalloc(ctx, &S.d_plist, LC * B * (size_t)(n_int ? n_int : 1));
+        rc |= dmalloc(ctx, &S.d_x, LC * B * n);
+        rc |= dmalloc(ctx, &S.d_vout, LC * B * nv);
         if (hipEventCreate(&S.e0) != hipSuccess || hipEventCreate(&S.e1) != hipSuccess ||
             hipEventCreate(&S.done) != hipSuccess) rc |= MIPX_EHIP;
     }
@@ -1571,7 +1600,7 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
         // every evaluated node may need pool rows for two children (four with the dive: the child
         // solved in place branches too); a step in flight has the same claim.  When the pool
         // cannot take a single node's children the search stops (status 4, stats.pool_exhausted).
-        const int64_t per = t->dive ? 4 : 2;
+        const int64_t per = 2 * (1 + (int64_t)t->dive);
         const int64_t room = ((int64_t)t->free_slots.size() - per * inflight) / per;
         if (room < want) {
             want = room > 0 ? room : 0;
@@ -1725,7 +1754,11 @@ int mipx_tree_set_dive(mipx_tree *t, int on) {
     if (on && t->cuts)
         return fail(t->ctx, MIPX_EINVAL, "mipx_tree_set_dive: a dive child would be solved before its parent's cut "
                                          "rounds; not available with cut rounds");
-    t->dive = on != 0;
+    if (on < 0 || on > kMaxDive) return fail(t->ctx, MIPX_EINVAL, "mipx_tree_set_dive: depth out of range (0..8)");
+    for (const StepBuf &S : t->buf)
+        if (S.in_flight) return fail(t->ctx, MIPX_EINVAL, "mipx_tree_set_dive: a step is in flight");
+    t->dive = on;
+    for (StepBuf &S : t->buf) layout_pack(t, S, 1 + on);
     return MIPX_OK;
 }
 

@@ -367,3 +367,57 @@ def test_in_place_dive_matches_oracle(n, m, seed, rule, gpu_ctx, oracle):
     if rule == 1:
         g = p.dive_batch(L, U, V, 1, ints, cost_l, cost_r, np.zeros(n, np.uint8))
         assert np.all(g['dive_var'] == -1)
+
+
+@pytest.mark.parametrize('n,m,seed', [(24, 10, 1), (64, 32, 0), (256, 128, 0), (300, 150, 1)])
+@pytest.mark.parametrize('rule,depth', [(0, 2), (1, 4), (0, 8)])
+def test_plunge_matches_oracle(n, m, seed, rule, depth, gpu_ctx, oracle):
+    """mipx_lp_plunge_batch: up to `depth` dive children in a row on one tableau (register tiles and
+    the HBM-streaming kernel), bit-identical to the oracle's restatement level by level; a level is
+    the LP an ordinary warm-started solve reaches from the level before with the plunge's bound moved."""
+    A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=seed)
+    p = _ffi.Problem(gpu_ctx, A, b, c)
+    root = p.solve_batch(l[None], u[None])
+    L, U, V = _children(A, b, c, l, u, root, 8)
+    B = len(L)
+    rng = np.random.default_rng(seed)
+    cost_l, cost_r = rng.uniform(0.5, 4.0, n), rng.uniform(0.5, 4.0, n)
+    has = np.ones(n, np.uint8)
+    g = p.dive_batch(L, U, V, rule, ints, cost_l, cost_r, has, depth=depth)
+    o = oracle.lp_solve_dive_batch(A, b, c, L, U, V, rule, ints, cost_l, cost_r, has, np.inf, depth=depth)
+    _assert_same_dive(g, o, f'plunge rule {rule} depth {depth}')
+    assert len(g['status']) == (depth + 1) * B and len(g['dive_var']) == depth * B
+    # depth 1 of the same call is the one-level dive
+    g1 = p.dive_batch(L, U, V, rule, ints, cost_l, cost_r, has)
+    for key in ('status', 'obj', 'iters', 'npivots'):
+        assert np.array_equal(g[key][:2 * B], g1[key]), key
+    assert np.array_equal(g['dive_var'][:B], g1['dive_var'])
+    # a level exists exactly where the level before decided to dive; chains really go deep
+    reached = np.zeros(depth + 1, int)
+    for lvl in range(depth):
+        went = g['dive_var'][lvl * B:(lvl + 1) * B] >= 0
+        assert np.array_equal(g['status'][(lvl + 1) * B:(lvl + 2) * B] >= 0, went)
+        if lvl > 0:   # no decision without a solved level
+            assert not np.any(went & (g['status'][lvl * B:(lvl + 1) * B] != 0))
+        reached[lvl + 1] = went.sum()
+    assert reached[min(depth, 2)] >= 1, reached
+    # level p + 1 = a warm-started solve from level p's basis with the accumulated bounds
+    Lc, Uc = L.copy(), U.copy()
+    for lvl in range(depth):
+        sel = np.where(g['dive_var'][lvl * B:(lvl + 1) * B] >= 0)[0]
+        if len(sel) == 0:
+            break
+        for k in sel:
+            v = g['dive_var'][lvl * B + k]
+            val = g['dive_val'][lvl * B + k]
+            assert val == g['x'][lvl * B + k][v]
+            if g['dive_dir'][lvl * B + k] == 0:
+                Uc[k, v] = np.floor(val)
+            else:
+                Lc[k, v] = np.ceil(val)
+        again = p.solve_batch(Lc[sel], Uc[sel], g['vstat'][lvl * B + sel])
+        child = (lvl + 1) * B + sel
+        assert np.array_equal(again['status'], g['status'][child])
+        fin = again['status'] == 0
+        assert np.allclose(again['obj'][fin], g['obj'][child][fin], rtol=0, atol=1e-6)
+        assert np.array_equal(g['npivots'][child], g['iters'][child])   # no refactorisation below the node

@@ -88,3 +88,46 @@ def test_anchor_table_entries_are_used_per_node(oracle):
                                     anchor_sel=np.full(B, -1, np.int32))
     assert np.all(r2['status'][:B] == 0) and np.all(r2['npivots'][:B] > 0)
     assert np.allclose(r2['obj'][:B], kids['obj'][ok], rtol=0, atol=1e-9)
+
+
+def test_oracle_plunge_levels_chain(oracle):
+    """The multi-level dive of the oracle: level p + 1 continues level p (same arrays, (depth + 1) *
+    batch rows); depth 1 is the one-level dive; each level is the optimum of the LP with the
+    accumulated bound moves (checked against a cold solve of that LP)."""
+    import numpy as np
+    from simple_mip_solver_amd.generators import random_dense_milp_arrays
+    n, m = 30, 12
+    A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=3)
+    root = oracle.lp_solve(A, b, c, l, u)
+    L, U, V = l[None].repeat(3, 0), u[None].repeat(3, 0), root['vstat'][None].repeat(3, 0)
+    for k in range(3):
+        j = int(np.argsort(-np.minimum(root['x'] - np.floor(root['x']), np.ceil(root['x']) - root['x']))[k])
+        U[k, j] = np.floor(root['x'][j])
+    has = np.ones(n, np.uint8); cl = np.ones(n); cr = np.ones(n)
+    d1 = oracle.lp_solve_dive_batch(A, b, c, L, U, V, 0, ints, cl, cr, has, np.inf)
+    d4 = oracle.lp_solve_dive_batch(A, b, c, L, U, V, 0, ints, cl, cr, has, np.inf, depth=4)
+    B = 3
+    assert len(d4['status']) == 5 * B and len(d4['dive_var']) == 4 * B
+    for key in ('status', 'obj', 'iters', 'npivots'):
+        assert np.array_equal(d4[key][:2 * B], d1[key])
+    assert np.array_equal(d4['dive_var'][:B], d1['dive_var'])
+    Lc, Uc = L.copy(), U.copy()
+    deepest = 0
+    for lvl in range(4):
+        for k in range(B):
+            v = d4['dive_var'][lvl * B + k]
+            child = (lvl + 1) * B + k
+            if v < 0:
+                assert d4['status'][child] == -1
+                continue
+            deepest = max(deepest, lvl + 1)
+            val = d4['dive_val'][lvl * B + k]
+            if d4['dive_dir'][lvl * B + k] == 0:
+                Uc[k, v] = np.floor(val)
+            else:
+                Lc[k, v] = np.ceil(val)
+            cold = oracle.lp_solve(A, b, c, Lc[k], Uc[k])
+            assert cold['status'] == d4['status'][child]
+            if cold['status'] == 0:
+                assert abs(cold['obj'] - d4['obj'][child]) < 1e-7
+    assert deepest >= 2

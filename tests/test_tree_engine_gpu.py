@@ -248,6 +248,44 @@ def test_step_hook_runs_inside_the_step_loop():
         t3.set_step_hook(lambda: False, 0)
 
 
+@pytest.mark.parametrize('rule,depth', [('most fractional', 3), ('pseudo cost', 4), ('pseudo cost', 8)])
+def test_plunge_reaches_the_same_optimum(rule, depth):
+    """mipx_tree_set_dive(depth > 1): up to `depth` dive children in a row per node.  Another node
+    order, the same optimum; every dive child is a real evaluated node (one LP each); the Python
+    driver passes the depth on."""
+    from simple_mip_solver_amd import _ffi
+    ctx = _ffi.default_context()
+    for n, m, seed in ((24, 10, 11), (30, 12, 3), (40, 16, 3), (48, 20, 0)):
+        A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=seed)
+        prob = _ffi.Problem(ctx, A, b, c)
+        out = {}
+        for d in (0, 1, depth):
+            t = _ffi.Tree(prob, ints, l, u, branch_rule=rule, max_batch=64, pool_capacity=1 << 17)
+            t.set_anchor_mode(True)
+            t.set_dive(d)
+            st = t.solve(mip_gap=0.0, frontier_batch=64, node_limit=200000)
+            out[d] = (st, t.solution() if st['has_solution'] else None)
+            t.close()
+        (s0, x0), (s1, x1), (sd, xd) = out[0], out[1], out[depth]
+        assert s0['status'] == s1['status'] == sd['status'] == 1, (s0, s1, sd)
+        assert isclose(s0['primal_bound'], sd['primal_bound'], abs_tol=1e-6)
+        assert sd['lp_solved'] == sd['evaluated_nodes'] and 0 < sd['dives'] < sd['evaluated_nodes']
+        assert sd['steps'] <= s1['steps'] + 2                                # no more steps than the one-level dive
+        assert np.max(np.abs(xd[ints] - np.round(xd[ints]))) <= 1e-4
+        assert np.all(A @ xd >= b - 1e-6) and isclose(float(c @ xd), sd['primal_bound'], abs_tol=1e-6)
+        prob.close()
+    with pytest.raises(_ffi.MipxError, match='MIPX_EINVAL'):
+        A, b, c, l, u, ints = random_dense_milp_arrays(24, 10, seed=10)
+        _ffi.Tree(_ffi.Problem(ctx, A, b, c), ints, l, u, max_batch=8).set_dive(9)
+    ref = BranchAndBound(random_model(30, 12, 3), PseudoCostBranchNode, pseudo_costs={}, gomory_cuts=False, frontier_batch=1)
+    ref.solve()
+    bb = BranchAndBound(random_model(30, 12, 3), PseudoCostBranchNode, pseudo_costs={}, gomory_cuts=False, frontier_batch=64,
+                        pool_capacity=1 << 15, dive=depth)
+    bb.solve()
+    assert bb.status == 'optimal' and isclose(bb.objective_value, ref.objective_value, abs_tol=1e-6)
+    assert bb._native_stats['dives'] > 0
+
+
 @pytest.mark.parametrize('rule', ['most fractional', 'pseudo cost'])
 def test_dive_reaches_the_same_optimum(rule):
     """mipx_tree_set_dive: the workgroup that solved a node also solves one child on the tableau it
