@@ -201,6 +201,18 @@ __global__ __launch_bounds__(256) void get_fraction_batch(FractionArgs g) {
     g.den[i] = dd;
 }
 
+constexpr int kGomoryGroup = 8;
+// dynamic LDS of gomory_cuts for n columns, ms allotted rows and `group` cuts at a time
+inline size_t gomory_lds_bytes(int n, int ms, int group) {
+    return ((size_t)group * (n + ms) + ms + 64) * 8 + (3 * (size_t)ms + n) * 4 + 64;
+}
+// the largest group whose staging fits 48 KiB of LDS
+inline int gomory_group(int n, int ms) {
+    int grp = kGomoryGroup;
+    while (grp > 1 && gomory_lds_bytes(n, ms, grp) > 48 * 1024) grp--;
+    return grp;
+}
+
 struct GomoryArgs {
     int m, n, batch;
     const double *A, *b;          // shared rows (m x n), rhs
@@ -214,6 +226,7 @@ struct GomoryArgs {
     double *pi, *pi0;             // batch x m x n, batch x m : raw GMI cuts  pi.x >= pi0
     double *safe_pi, *safe_pi0;   // rounded ('over' coefficients, 'under' right-hand side)
     int chunks = 1;               // workgroups per node: cut c of a node is worked out by workgroup c % chunks
+    int group = 1;                // cuts a workgroup substitutes the slacks of at once (<= kGomoryGroup; LDS: gomory_lds_bytes)
     // ---- frontier engine with cut rounds (all optional) ------------------------------------------
     // per-node cut rows, as in LpArgs: node k has m + ncut[k] rows, row m + i = cut cut_ids[k * cut_stride + i]
     const int32_t *ncut = nullptr, *cut_ids = nullptr;
@@ -246,13 +259,15 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
     const int ms = g.mstride ? g.mstride : m0;     // rows allotted per node in the strided arrays
     const int32_t *cids = g.ncut ? g.cut_ids + (size_t)node * g.cut_stride : nullptr;
     const double INF = __builtin_huge_val();
-    // dynamic LDS carve (sized for ms rows): pi_var[n] | ps[ms] | red[64] | order[ms] | bvar[ms] | nvar[n]
+    // dynamic LDS carve (sized for ms rows): group x (pi_var[n] | ps[ms]) | cut_f0[ms] | red[64] |
+    // order[ms] | bvar[ms] | nvar[n] | cut_rank[ms]      (gomory_lds_bytes)
     double *pi_var = (double *)smem_raw;
-    double *ps = pi_var + n;
-    double *red = ps + ms;
+    double *cut_f0 = pi_var + (size_t)g.group * (n + ms);
+    double *red = cut_f0 + ms;
     int *order = (int *)(red + 64);   // order[rank] = tableau row
     int *bvar_s = order + ms;
     int *nvar_s = bvar_s + ms;
+    int *cut_rank = nvar_s + n;
     const int32_t *idx = g.idx + (size_t)node * (2 * n + ms);
     const double *T = g.T + (size_t)node * ms * n;
     const double *x = g.x + (size_t)node * n;
@@ -282,6 +297,8 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
         order[rank] = i;
     }
     __syncthreads();
+    // ---- which cuts there are (uniform over the workgroup), and which are this workgroup's ---------
+    // rows whose basic variable is an integer structural with a fractional value (f0 in [0.01, 0.99])
     int ncuts = 0;
     for (int rank = 0; rank < m; rank++) {
         const int r = order[rank];
@@ -295,127 +312,166 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
             f0 = xv - fl;
             if (f0 < kGoodEps || f0 + kGoodEps > 1.0) gen = false;
         }
-        if (!gen) continue;  // uniform: depends on shared data only
-        if (ncuts % g.chunks != chunk) { ncuts++; continue; }  // another workgroup's cut
-        for (int j = tid; j < n; j += NT) pi_var[j] = 0.0;
-        for (int i = tid; i < m; i += NT) ps[i] = 0.0;
+        if (!gen) continue;
+        if (tid == 0) { cut_rank[ncuts] = rank; cut_f0[ncuts] = f0; }
+        ncuts++;
+    }
+    __syncthreads();
+    // ---- this workgroup's cuts, GRP at a time: the slack substitution of a group reads every row of
+    // A once for all of them (one cut at a time re-read the 256 KiB of A from L2 per cut: the kernel
+    // was bound by that).  Per cut the arithmetic and its order are unchanged.
+    const int GRP = g.group;
+    for (int c0 = chunk; c0 < ncuts; c0 += g.chunks * GRP) {
+        int gc = 0;   // cuts in this group: c0, c0 + chunks, ...
+        while (gc < GRP && c0 + gc * g.chunks < ncuts) gc++;
+        for (int q = 0; q < gc; q++) {
+            double *pv = pi_var + (size_t)q * (n + ms), *psq = pv + n;
+            for (int j = tid; j < n; j += NT) pv[j] = 0.0;
+            for (int i = tid; i < m; i += NT) psq[i] = 0.0;
+        }
         __syncthreads();
-        const double *Tr = T + (size_t)r * n;
-        for (int j = tid; j < n; j += NT) {
-            const int var = nvar_s[j];
-            const double a = Tr[j];
-            const double cont = a > 0.0 ? a / f0 : -a / (1.0 - f0);
-            if (var < n) {
-                double val = cont;
-                if (g.is_int[var]) {
-                    const double f = a - floor(a);
-                    val = f <= f0 ? f / f0 : (1.0 - f) / (1.0 - f0);
+        for (int q = 0; q < gc; q++) {
+            const int cq = c0 + q * g.chunks;
+            const int r = order[cut_rank[cq]];
+            const double f0 = cut_f0[cq];
+            double *pv = pi_var + (size_t)q * (n + ms), *psq = pv + n;
+            const double *Tr = T + (size_t)r * n;
+            for (int j = tid; j < n; j += NT) {
+                const int var = nvar_s[j];
+                const double a = Tr[j];
+                const double cont = a > 0.0 ? a / f0 : -a / (1.0 - f0);
+                if (var < n) {
+                    double val = cont;
+                    if (g.is_int[var]) {
+                        const double f = a - floor(a);
+                        val = f <= f0 ? f / f0 : (1.0 - f) / (1.0 - f0);
+                    }
+                    pv[var] = val;
+                } else {
+                    psq[var - n] = cont;
                 }
-                pi_var[var] = val;
-            } else {
-                ps[var - n] = cont;
             }
         }
         __syncthreads();
         // coefs = pi + A' ps, accumulated row by row (the order of the reference's sparse product);
         // the node's cut rows follow the shared ones
-        double *out_pi = g.pi ? g.pi + ((size_t)node * ms + ncuts) * n : nullptr;
         for (int var = tid; var < n; var += NT) {
-            double acc = 0.0;
-            // (same order of additions; the loads of 16 rows are issued before the first is consumed:
-            // the plain loop paid one L2 latency per row, 20 us per cut at m = 128)
+            double acc[kGomoryGroup];
+#pragma unroll
+            for (int q = 0; q < kGomoryGroup; q++) acc[q] = 0.0;
             int i = 0;
-            for (; i + 16 <= m0; i += 16) {
-                double a[16];
+            for (; i + 8 <= m0; i += 8) {   // (the loads of 8 rows are issued before the first is consumed)
+                double a[8];
 #pragma unroll
-                for (int k = 0; k < 16; k++) a[k] = g.A[(size_t)(i + k) * n + var];
+                for (int k = 0; k < 8; k++) a[k] = g.A[(size_t)(i + k) * n + var];
 #pragma unroll
-                for (int k = 0; k < 16; k++) acc = acc + a[k] * ps[i + k];
-            }
-            for (; i < m0; i++) acc = acc + g.A[(size_t)i * n + var] * ps[i];
-            for (; i < m; i++) acc = acc + g.cut_pi[(size_t)cids[i - m0] * n + var] * ps[i];
-            const double coef = pi_var[var] + acc;
-            if (out_pi) out_pi[var] = coef;
-            pi_var[var] = coef;   // keep for the rounding below
-        }
-        // rhs = 1 + ps . b with a fold-in-half tree over the next power of two (wave 0)
-        if (wave == 0) {
-            int m2 = 1;
-            while (m2 < m) m2 <<= 1;
-            // each lane folds its strided elements first (j and j + m2/2 ... down to 64 lanes)
-            double part = 0.0;
-            auto rhs_of = [&](int j) { return j < m0 ? g.b[j] : g.cut_pi0[cids[j - m0]]; };
-            if (m2 <= 64) {
-                part = lane < m ? ps[lane] * rhs_of(lane) : 0.0;
-                for (int h = m2 / 2; h >= 1; h >>= 1) part = part + __shfl_down(part, h, 64);
-            } else {
-                // lane holds elements lane + 64*k: fold the k levels in registers, then across lanes
-                double e[16];
-                const int per = m2 / 64;  // <= 16 for m <= 1024
-                for (int k = 0; k < 16; k++) {
-                    const int j = lane + 64 * k;
-                    e[k] = (k < per && j < m) ? ps[j] * rhs_of(j) : 0.0;
+                for (int k = 0; k < 8; k++) {
+#pragma unroll
+                    for (int q = 0; q < kGomoryGroup; q++)
+                        if (q < gc) acc[q] = acc[q] + a[k] * pi_var[(size_t)q * (n + ms) + n + i + k];
                 }
-                for (int h = per / 2; h >= 1; h >>= 1)
-                    for (int k = 0; k < h; k++) e[k] = e[k] + e[k + h];
-                part = e[0];
-                for (int h = 32; h >= 1; h >>= 1) part = part + __shfl_down(part, h, 64);
             }
-            if (lane == 0) {
-                const double rhs = 1.0 + part;
-                if (g.pi0) g.pi0[(size_t)node * ms + ncuts] = rhs;
-                if (g.row_idx) g.row_idx[(size_t)node * ms + ncuts] = rank;
-                red[0] = rhs;
+            for (; i < m; i++) {
+                const double a = i < m0 ? g.A[(size_t)i * n + var] : g.cut_pi[(size_t)cids[i - m0] * n + var];
+#pragma unroll
+                for (int q = 0; q < kGomoryGroup; q++)
+                    if (q < gc) acc[q] = acc[q] + a * pi_var[(size_t)q * (n + ms) + n + i];
+            }
+#pragma unroll
+            for (int q = 0; q < kGomoryGroup; q++) {
+                if (q < gc) {
+                    double *pv = pi_var + (size_t)q * (n + ms);
+                    const double coef = pv[var] + acc[q];
+                    if (g.pi) g.pi[((size_t)node * ms + (c0 + q * g.chunks)) * n + var] = coef;
+                    pv[var] = coef;   // keep for the rounding below
+                }
             }
         }
         __syncthreads();
-        // ---- numerically safe rounding (estimate 'over'; rhs 'under') -----------------------
-        // scale = min_j |1 / coef_j|
-        double smin = INF;
-        bool any = false;
-        for (int var = tid; var < n; var += NT) {
-            const double c = pi_var[var];
-            any |= c != 0.0;
-            smin = fmin(smin, fabs(1.0 / c));
-        }
-        // block reduction (min is order independent)
-        smin = -wave_max_f64(-smin);
-        const int anyw = __any(any);
-        if (lane == 0) { red[1 + wave] = smin; red[33 + wave] = anyw; }
-        __syncthreads();
-        double scale = INF;
-        bool nonzero = false;
-        for (int wv = 0; wv < NT / 64; wv++) { scale = fmin(scale, red[1 + wv]); nonzero |= red[33 + wv] != 0.0; }
-        // where the rounded cut goes: row ncuts of the node's block of safe_pi, or (engine) the next
-        // free row of the node's pool slab; a full slab drops the cut
-        double *out_sp, *out_s0;
-        if (g.slab_pi != nullptr) {
-            const int row = g.slab_n[node] + ncuts;
-            if (row >= g.slab_rows) { ncuts++; continue; }   // (uniform)
-            out_sp = g.slab_pi + ((size_t)node * g.slab_rows + row) * n;
-            out_s0 = g.slab_pi0 + (size_t)node * g.slab_rows + row;
-        } else {
-            out_sp = g.safe_pi + ((size_t)node * ms + ncuts) * n;
-            out_s0 = g.safe_pi0 + (size_t)node * ms + ncuts;
-        }
-        if (!nonzero) {
-            for (int var = tid; var < n; var += NT) out_sp[var] = pi_var[var];
-            if (tid == 0) *out_s0 = red[0];
-        } else {
+        for (int q = 0; q < gc; q++) {
+            const int cq = c0 + q * g.chunks;
+            const int rank = cut_rank[cq];
+            double *pv = pi_var + (size_t)q * (n + ms), *psq = pv + n;
+            // rhs = 1 + ps . b with a fold-in-half tree over the next power of two (wave 0)
+            if (wave == 0) {
+                int m2 = 1;
+                while (m2 < m) m2 <<= 1;
+                double part = 0.0;
+                auto rhs_of = [&](int j) { return j < m0 ? g.b[j] : g.cut_pi0[cids[j - m0]]; };
+                if (m2 <= 64) {
+                    part = lane < m ? psq[lane] * rhs_of(lane) : 0.0;
+                    for (int h = m2 / 2; h >= 1; h >>= 1) part = part + __shfl_down(part, h, 64);
+                } else {
+                    // lane holds elements lane + 64*k: fold the k levels in registers, then across lanes
+                    double e[16];
+                    const int per = m2 / 64;  // <= 16 for m <= 1024
+                    for (int k = 0; k < 16; k++) {
+                        const int j = lane + 64 * k;
+                        e[k] = (k < per && j < m) ? psq[j] * rhs_of(j) : 0.0;
+                    }
+                    for (int h = per / 2; h >= 1; h >>= 1)
+                        for (int k = 0; k < h; k++) e[k] = e[k] + e[k + h];
+                    part = e[0];
+                    for (int h = 32; h >= 1; h >>= 1) part = part + __shfl_down(part, h, 64);
+                }
+                if (lane == 0) {
+                    const double rhs = 1.0 + part;
+                    if (g.pi0) g.pi0[(size_t)node * ms + cq] = rhs;
+                    if (g.row_idx) g.row_idx[(size_t)node * ms + cq] = rank;
+                    red[0] = rhs;
+                }
+            }
+            __syncthreads();
+            // ---- numerically safe rounding (estimate 'over'; rhs 'under') -----------------------
+            // scale = min_j |1 / coef_j|
+            double smin = INF;
+            bool any = false;
             for (int var = tid; var < n; var += NT) {
-                const double coef = pi_var[var] * scale;
-                double nn, dd;
-                safe_coef_dev(coef, g.max_term, kEstOver, nn, dd);
-                out_sp[var] = nn / dd;
+                const double c = pv[var];
+                any |= c != 0.0;
+                smin = fmin(smin, fabs(1.0 / c));
             }
-            if (tid == 0) {
-                double n0, d0;
-                get_fraction_dev(red[0] * scale, 1e3, kEstUnder, n0, d0);
-                *out_s0 = n0 / d0;
+            // block reduction (min is order independent)
+            smin = -wave_max_f64(-smin);
+            const int anyw = __any(any);
+            if (lane == 0) { red[1 + wave] = smin; red[33 + wave] = anyw; }
+            __syncthreads();
+            double scale = INF;
+            bool nonzero = false;
+            for (int wv = 0; wv < NT / 64; wv++) { scale = fmin(scale, red[1 + wv]); nonzero |= red[33 + wv] != 0.0; }
+            // where the rounded cut goes: row cq of the node's block of safe_pi, or (engine) the next
+            // free rows of the node's pool slab; a full slab drops the cut
+            double *out_sp = nullptr, *out_s0 = nullptr;
+            if (g.slab_pi != nullptr) {
+                const int row = g.slab_n[node] + cq;
+                if (row < g.slab_rows) {
+                    out_sp = g.slab_pi + ((size_t)node * g.slab_rows + row) * n;
+                    out_s0 = g.slab_pi0 + (size_t)node * g.slab_rows + row;
+                }
+            } else {
+                out_sp = g.safe_pi + ((size_t)node * ms + cq) * n;
+                out_s0 = g.safe_pi0 + (size_t)node * ms + cq;
             }
+            if (out_sp != nullptr) {   // (uniform)
+                if (!nonzero) {
+                    for (int var = tid; var < n; var += NT) out_sp[var] = pv[var];
+                    if (tid == 0) *out_s0 = red[0];
+                } else {
+                    for (int var = tid; var < n; var += NT) {
+                        const double coef = pv[var] * scale;
+                        double nn, dd;
+                        safe_coef_dev(coef, g.max_term, kEstOver, nn, dd);
+                        out_sp[var] = nn / dd;
+                    }
+                    if (tid == 0) {
+                        double n0, d0;
+                        get_fraction_dev(red[0] * scale, 1e3, kEstUnder, n0, d0);
+                        *out_s0 = n0 / d0;
+                    }
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        ncuts++;
     }
     // (engine: the new slab rows join the node's pool in pool_append, after every workgroup of the
     // node is done with slab_n)

@@ -644,7 +644,8 @@ int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
         ga.active = S.cs_active;
         ga.slab_pi = S.slab_pi; ga.slab_pi0 = S.slab_pi0;
         ga.slab_n = S.cs_state + (size_t)mipx::CF_SLAB_N * B; ga.slab_rows = t->slab_rows;
-        const size_t lds2 = ((size_t)n + t->mrows + 64) * 8 + (2 * (size_t)t->mrows + n) * 4 + 64;
+        ga.group = mipx::gomory_group(n, t->mrows);
+        const size_t lds2 = mipx::gomory_lds_bytes(n, t->mrows, ga.group);
         hipLaunchKernelGGL((mipx::gomory_cuts<256>), dim3(B * ga.chunks), dim3(256), lds2, st, ga);
         HIP_TRY(ctx, hipGetLastError());
         mipx::PoolAppendArgs pa;
