@@ -40,6 +40,17 @@
  *      over until a non-degenerate step (anti-cycling);
  *      rank-1 tableau update with explicit fma; the pivot row is scaled by the reciprocal
  *      1/p (one division per pivot), as the kernel does.
+ *   3'. pricing (which violated row leaves).  Pricing 0 (the HBM-streaming kernel K1b): the largest
+ *      violation, as above.  Pricing 1 (the register-tile kernel K1: every shape with m <= 192 and
+ *      n <= 256): dual steepest edge -- the largest viol^2 / w_i, w_i the squared norm of row i of
+ *      the full tableau [I | T] (>= 1).  w is set after step 2 (w_i = 1 + sum_j T_ij^2, fold-in-half),
+ *      carried through pivots by the exact recurrence for the row operations of a pivot on (r, q):
+ *      tau_i = sum_j T_ij T_rj (before the pivot, fold-in-half), ratio_i = T_iq * (1/p),
+ *      w_i <- max(1, fma(ratio_i, fma(ratio_i, w_r, -2 tau_i), w_i)), w_r <- max(1, (w_r (1/p)) (1/p)),
+ *      and recomputed from the tableau after every 64th iteration since they were last exact (the
+ *      recurrence drifts over long cold solves).  Bland's rule ignores the weights.  The weights
+ *      survive an in-place dive (same tableau).  On the node LPs of the 256 x 128 benchmark tree this
+ *      takes 20 % fewer iterations than the largest-violation rule, on its root 10 x fewer.
  *   4. status 0 optimal / 1 primal infeasible / 2 unbounded (optimum depends on M) /
  *      3 iteration limit -- the Clp codes the reference reads (base_node.py:274-275,
  *      pseudo_cost.py:86).
@@ -87,6 +98,15 @@ void mipx_oracle_set_dump(double *T, double *vec, int32_t *idx) {
 static const double *g_anchor_T = 0, *g_anchor_vec = 0;
 static const int32_t *g_anchor_idx = 0;
 static int g_refactor_only = 0;
+/* pricing rule of the node LPs: -1 = what the GPU path runs for the shape (1 where the register-tile
+ * kernel takes it: m <= 192 and n <= 256 with the tile table of csrc/mipx.hip, else 0) */
+static int g_pricing = -1;
+void mipx_oracle_set_pricing(int pricing) { g_pricing = pricing; }
+static int pricing_for(int m, int n) {
+    if (g_pricing >= 0) return g_pricing;
+    return ((m <= 32 && n <= 64) || (m <= 64 && n <= 128) || (m <= 128 && n <= 256) || (m <= 192 && n <= 256)) ? 1 : 0;
+}
+#define MIPX_DSE_REFRESH 64
 void mipx_oracle_set_anchor(const double *T, const double *vec, const int32_t *idx) {
     g_anchor_T = T; g_anchor_vec = vec; g_anchor_idx = idx;
 }
@@ -285,6 +305,20 @@ static int lp_solve_impl(int m, int n, const double *A, const double *b, const d
         bb[i] = 0.0 - fold_sum(buf, n2);
     }
 
+    /* 3'. dual steepest edge weights (pricing 1): squared norms of the rows of [I | T] */
+    const int dse = pricing_for(m, n) == 1;
+    double *wgt = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    double *tau = (double *)malloc(sizeof(double) * (size_t)(m + 1));
+    int wage = 0; /* iterations since the weights were exact */
+    if (dse && !g_refactor_only) {
+        for (int i = 0; i < m; i++) {
+            const double *Ti = t.T + (size_t)i * n;
+            for (int j = 0; j < n; j++) buf[j] = Ti[j] * Ti[j];
+            for (int j = n; j < n2; j++) buf[j] = 0.0;
+            wgt[i] = 1.0 + fold_sum(buf, n2);
+        }
+    }
+
     /* 3. dual simplex */
     int iters = 0, status = -1;
     int degen = 0; /* consecutive degenerate steps; > m+n switches to Bland's rule (anti-cycling) */
@@ -311,6 +345,7 @@ next_pass:
                 else if (!isinf(up) && a > up + MIPX_PTOL) { level = 1; viol = a - up; sg = -1; }
             }
             if (level == 0) continue;
+            if (dse) viol = viol * viol / wgt[i];
             if (bland) { level = 1; viol = 0.0; } /* Bland: lowest variable index among violated */
             int better = 0;
             if (r < 0) better = 1;
@@ -371,6 +406,23 @@ next_pass:
             else { la = 0.0; lb = 1.0; newside = 2; }
             const double p = Tr[q];
             const double pinv = 1.0 / p;
+            if (dse) { /* the weights after the row operations of this pivot */
+                for (int i = 0; i < m; i++) {
+                    const double *Ti = t.T + (size_t)i * n;
+                    for (int j = 0; j < n; j++) buf[j] = Ti[j] * Tr[j];
+                    for (int j = n; j < n2; j++) buf[j] = 0.0;
+                    tau[i] = fold_sum(buf, n2);
+                }
+                const double wr = wgt[r];
+                for (int i = 0; i < m; i++) {
+                    if (i == r) continue;
+                    const double ratio = t.T[(size_t)i * n + q] * pinv;
+                    const double w = fma(ratio, fma(ratio, wr, -2.0 * tau[i]), wgt[i]);
+                    wgt[i] = w < 1.0 ? 1.0 : w;
+                }
+                const double w = (wr * pinv) * pinv;
+                wgt[r] = w < 1.0 ? 1.0 : w;
+            }
             const double ta = (ba[r] - la) * pinv, tb = (bb[r] - lb) * pinv;
             for (int i = 0; i < m; i++) {
                 if (i == r) continue;
@@ -384,6 +436,15 @@ next_pass:
             nb_up[q] = (int8_t)newside;
             va[q] = la; vb[q] = lb;
             iters++; npiv++;
+            if (dse && ++wage == MIPX_DSE_REFRESH) { /* exact again, from the tableau after the pivot */
+                wage = 0;
+                for (int i = 0; i < m; i++) {
+                    const double *Ti = t.T + (size_t)i * n;
+                    for (int j = 0; j < n; j++) buf[j] = Ti[j] * Ti[j];
+                    for (int j = n; j < n2; j++) buf[j] = 0.0;
+                    wgt[i] = 1.0 + fold_sum(buf, n2);
+                }
+            }
         }
     }
 
@@ -484,6 +545,7 @@ done:
 
     free(t.T); free(t.beta0); free(t.d); free(t.bvar); free(t.nvar);
     free(atup); free(wantb); free(nb_up); free(ba); free(bb); free(buf); free(va); free(vb);
+    free(wgt); free(tau);
     return 0;
 }
 

@@ -110,6 +110,21 @@ def lp_solve_dive_batch(A, b, c, l, u, vstat, rule, int_idx, cost_l, cost_r, has
                 dive_dir=ddir, dive_val=dval)
 
 
+class pricing:
+    """Context manager: force the pricing rule of the oracle's node LPs (0 largest violation -- what
+    the HBM-streaming kernel runs --, 1 dual steepest edge -- the register-tile kernel); the default
+    (-1) follows the GPU path's choice by shape."""
+
+    def __init__(self, rule):
+        self.rule = int(rule)
+
+    def __enter__(self):
+        lib().mipx_oracle_set_pricing(C.c_int(self.rule))
+
+    def __exit__(self, *exc):
+        lib().mipx_oracle_set_pricing(C.c_int(-1))
+
+
 def lp_solve(A, b, c, l, u, vstat=None, max_iter=0):
     r = lp_solve_batch(A, b, c, np.asarray(l, float)[None], np.asarray(u, float)[None],
                        None if vstat is None else np.asarray(vstat, np.int8)[None], max_iter)

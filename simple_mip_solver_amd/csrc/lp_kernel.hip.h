@@ -106,6 +106,7 @@ struct LpArgs {
 };
 
 constexpr double kVarEps = 1e-4;  // utils/tolerance.py:2 variable_epsilon
+constexpr int kDseRefresh = 64;   // iterations after which the steepest-edge weights are recomputed from the tableau
 
 #ifdef MIPX_KPROF
 #define KPROF_MARK(k)                                  \
@@ -116,6 +117,14 @@ constexpr double kVarEps = 1e-4;  // utils/tolerance.py:2 variable_epsilon
     } while (0)
 #else
 #define KPROF_MARK(k) do { } while (0)
+#endif
+// MIPX_KPROF_OUT: the slots of the refactorisation marks time the output section instead
+#ifdef MIPX_KPROF_OUT
+#define KPROF_REF_MARK(k) do { } while (0)
+#define KPROF_OUT_MARK(k) KPROF_MARK(k)
+#else
+#define KPROF_REF_MARK(k) KPROF_MARK(k)
+#define KPROF_OUT_MARK(k) do { } while (0)
 #endif
 #ifdef MIPX_KPROF_SETUP
 #define KPROF_SETUP_MARK(k) KPROF_MARK(k)
@@ -354,6 +363,8 @@ struct Smem {
     double beta0[MP];
     double ba[4 * NW * R];
     double bb[4 * NW * R];
+    double wgt[4 * NW * R];   // dual steepest edge: exact row weights (set-up, refresh) on their way to the control wave
+    double tau[4 * NW * R];   //   and tau_i = sum_j T_ij T_rj of the current pivot row
     MailA mbA;
     MailB mbB;
     int bvar[MP];
@@ -436,12 +447,14 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
 // rank-1 update of the register tableau for the pivot on (r, q): this lane's part of column q
 // is in al[] (MIPX_PUBLISH_COL), row r in s.row.  Row r and column q come out of the fma sweep as
 // junk and are overwritten right after it.
-#define MIPX_UPDATE_T(r_, q_, pinv_)                                                        \
+#define MIPX_ROW_LDS(jj_) s.row[MIPX_COL(jj_)]
+#define MIPX_ROW_REG(jj_) rw[jj_]
+#define MIPX_UPDATE_T(r_, q_, pinv_, rowsrc_)                                               \
     do {                                                                                    \
         const int rg_ = (r_) % NG, rl_ = (r_) / NG;                                         \
         const int qcl_ = ((q_)&31) >> 1, qjj_ = 2 * ((q_) >> 5) + ((q_)&1);                 \
         double rh[C];                                                                       \
-        _Pragma("unroll") for (int jj = 0; jj < C; jj++) rh[jj] = s.row[MIPX_COL(jj)] * (pinv_); \
+        _Pragma("unroll") for (int jj = 0; jj < C; jj++) rh[jj] = rowsrc_(jj) * (pinv_);    \
         _Pragma("unroll") for (int ii = 0; ii < R; ii++) {                                  \
             _Pragma("unroll") for (int jj = 0; jj < C; jj++)                                \
                 T[ii][jj] = fma(-al[ii], rh[jj], T[ii][jj]);                                \
@@ -500,6 +513,45 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
         }                                                                                   \
     } while (0)
 
+// Tableau waves: out_[ii] = fold-in-half sum over the padded columns of term_(ii, jj), valid at the
+// lanes with cl == 0.  Column j = 32*pp + 2*cl + e, so the levels of the canonical tree are pp (in the
+// thread, per e), then the column lanes cl + 8, 4, 2, 1 (DPP inside the 16-lane row group), then e.
+#define MIPX_ROW_FOLD(term_, out_)                                                          \
+    do {                                                                                    \
+        double f0_[R], f1_[R];                                                              \
+        _Pragma("unroll") for (int ii = 0; ii < R; ii++) {                                  \
+            double t_[C];                                                                   \
+            _Pragma("unroll") for (int jj = 0; jj < C; jj++) t_[jj] = term_(ii, jj);        \
+            _Pragma("unroll") for (int h = C / 4; h >= 1; h >>= 1) {                        \
+                _Pragma("unroll") for (int k = 0; k < 2 * h; k++) t_[k] = t_[k] + t_[k + 2 * h]; \
+            }                                                                               \
+            f0_[ii] = t_[0];                                                                \
+            f1_[ii] = t_[1];                                                                \
+        }                                                                                   \
+        _Pragma("unroll") for (int ii = 0; ii < R; ii++) {                                  \
+            f0_[ii] = f0_[ii] + dpp_f64<0x108, 0xf>(f0_[ii]);                               \
+            f1_[ii] = f1_[ii] + dpp_f64<0x108, 0xf>(f1_[ii]);                               \
+            f0_[ii] = f0_[ii] + dpp_f64<0x104, 0xf>(f0_[ii]);                               \
+            f1_[ii] = f1_[ii] + dpp_f64<0x104, 0xf>(f1_[ii]);                               \
+            f0_[ii] = f0_[ii] + dpp_f64<0x102, 0xf>(f0_[ii]);                               \
+            f1_[ii] = f1_[ii] + dpp_f64<0x102, 0xf>(f1_[ii]);                               \
+            f0_[ii] = f0_[ii] + dpp_f64<0x101, 0xf>(f0_[ii]);                               \
+            f1_[ii] = f1_[ii] + dpp_f64<0x101, 0xf>(f1_[ii]);                               \
+            out_[ii] = f0_[ii] + f1_[ii];                                                   \
+        }                                                                                   \
+    } while (0)
+#define MIPX_TERM_SQ(ii_, jj_) (T[ii_][jj_] * T[ii_][jj_])
+#define MIPX_TERM_ROW(ii_, jj_) (T[ii_][jj_] * rw[jj_])
+// exact steepest-edge weights of this wave's rows: 1 + sum_j T_ij^2 (the row of [I | T])
+#define MIPX_EXACT_WEIGHTS()                                                                \
+    do {                                                                                    \
+        double wq_[R];                                                                      \
+        MIPX_ROW_FOLD(MIPX_TERM_SQ, wq_);                                                   \
+        if (cl == 0) {                                                                      \
+            _Pragma("unroll") for (int ii = 0; ii < R; ii++) s.wgt[MIPX_ROW(ii)] = 1.0 + wq_[ii]; \
+        }                                                                                   \
+    } while (0)
+
 // (a) the control wave's choice of the leaving row, or of the end of the solve, published for everybody:
 // largest violation (violations of the symbolic bound M first), ties -> lowest variable index
 #define MIPX_LEAVE_SELECT()                                                                  \
@@ -517,7 +569,8 @@ _Pragma("unroll")                                                               
                 const double lo = rLo[kk], up = rUp[kk], a = rBa[kk];                            \
                 const bool lowv = a < lo - kPTol;                                                \
                 const bool upv = !lowv & (a > up + kPTol); /* up = +inf never fires */           \
-                const double viol = bland ? 0.0 : (lowv ? lo - a : a - up);                      \
+                const double v0_ = lowv ? lo - a : a - up; /* (dual steepest edge: viol^2 / w) */\
+                const double viol = bland ? 0.0 : v0_ * v0_ / rW[kk];                            \
                 const int pay = ((rM[kk] >> 2) << 16) | (lowv ? 0 : 0x8000) | i;                 \
                 keep_max(bk, bp, viol, pay, (i < m) & (lowv | upv));                             \
             }                                                                                    \
@@ -541,6 +594,7 @@ _Pragma("unroll")                                                               
                         if (a < lo - kPTol) { level = 1; viol = lo - a; sg = 1; }                \
                         else if (!isinf(up) && a > up + kPTol) { level = 1; viol = a - up; sg = -1; }\
                     }                                                                            \
+                    viol = viol * viol / rW[kk];                                                 \
                     if (bland && level > 0) { level = 1; viol = 0.0; }                           \
                     anybb |= bM > kBTol;                                                         \
                     const int pay = (v << 16) | (sg < 0 ? 0x8000 : 0) | i;                       \
@@ -575,6 +629,7 @@ _Pragma("unroll")                                                               
             sel_b0 = readlane_f64(t2, rl);                                                       \
             sel_ba = readlane_f64(t3, rl);                                                       \
             sel_bb = readlane_f64(t4, rl);                                                       \
+            { double t5; MIPX_PICK(t5, rW, PI, rk); sel_w = readlane_f64(t5, rl); }              \
             const int lvv = __builtin_amdgcn_readlane(tm, rl) >> 2;                              \
             double la_, lb_;                                                                     \
             int newside;                                                                         \
@@ -649,6 +704,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     double cD[PJ];   // reduced cost
     int cM[PJ];      // nonbasic variable << 3 | fixed << 2 | side
     double rB0[PI], rBa[PI], rBb[PI], rLo[PI], rUp[PI];
+    double rW[PI];   // dual steepest edge weight of the row: squared norm of its row of [I | T]
     int rM[PI];      // basic variable << 2 | pivoted by the refactorisation << 1 | wanted basic
     const size_t src = g.slot ? (size_t)g.slot[node] : (size_t)node;
     const double *gA = g.A + (size_t)node * g.A_stride;
@@ -807,6 +863,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         rB0[kk] = i < MP ? s.beta0[ic] : 0.0;
         rBa[kk] = 0.0;
         rBb[kk] = 0.0;
+        rW[kk] = 1.0;
         rLo[kk] = st ? s.lo[st ? v : 0] : 0.0;
         rUp[kk] = st ? s.up[st ? v : 0] : INF;
         rM[kk] = (v << 2) | ((v >= 0 && s.wantb[v < 0 ? 0 : v]) ? 1 : 0);
@@ -896,12 +953,12 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                 } else if (lane == 0) {
                     s.mbA.win = -1;  // singular: the variable stays nonbasic
                 }
-                KPROF_MARK(9);
+                KPROF_REF_MARK(9);
                 __syncthreads();  // A: row chosen
                 __syncthreads();  // B: row published
-                KPROF_MARK(10);
+                KPROF_REF_MARK(10);
                 if (rr != kNoCand) MIPX_UPDATE_COLS(q, pinv, lvmeta);
-                KPROF_MARK(12);
+                KPROF_REF_MARK(12);
             }
         } else {
             if (nw > 0) MIPX_PUBLISH_COL(__builtin_amdgcn_readfirstlane(s.wlist[0]));
@@ -913,16 +970,16 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                 read_mail(s.mbA, r, lvmeta, pinv);
                 if (r >= 0) MIPX_EXTRACT_ROW(r);
                 __syncthreads();  // B
-                KPROF_MARK(10);
+                KPROF_REF_MARK(10);
                 const int qn = w + 1 < nw ? __builtin_amdgcn_readfirstlane(s.wlist[w + 1 < nw ? w + 1 : 0]) : -1;
                 if (r >= 0 && qn >= 0) MIPX_PUBLISH_NEXT_COL(r, pinv, qn);  // out before the sweep
-                KPROF_MARK(14);
-                if (r >= 0) MIPX_UPDATE_T(r, q, pinv);
+                KPROF_REF_MARK(14);
+                if (r >= 0) MIPX_UPDATE_T(r, q, pinv, MIPX_ROW_LDS);
                 if (qn >= 0) {
                     if (r >= 0) MIPX_READ_COL();
                     else MIPX_PUBLISH_COL(qn);  // (singular column: nothing changed, plain publish)
                 }
-                KPROF_MARK(13);
+                KPROF_REF_MARK(13);
             }
         }
     }
@@ -1026,6 +1083,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                     for (int ii = 0; ii < R; ii++) s.bb[MIPX_ROW(ii)] = 0.0 - (s0[ii] + s1[ii]);
                 }
             }
+            MIPX_EXACT_WEIGHTS();   // the steepest-edge weights the solve starts with
         }
         __syncthreads();
         KPROF_MARK(7);
@@ -1037,6 +1095,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     size_t onode = (size_t)node;
     int dvar = -1, ddir = 0;     // control wave: the dive's branching variable, direction,
     double dbound = 0.0;         //   and the bound that moves (floor / ceil of its value)
+    int wage = 0;                // iterations since the steepest-edge weights were exact (both roles count)
 #pragma clang loop unroll(disable)
     for (;;) {
     if (solve) {
@@ -1051,6 +1110,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
             const int nfk0 = nfake;
             int nfk = nfk0;
             double sel_b0 = 0.0, sel_ba = 0.0, sel_bb = 0.0;  // border values of row r
+            double sel_w = 1.0;                               //   and its steepest-edge weight
             int sel_win = 0, sel_lvmeta = 0;
             double sel_la = 0.0;
             if (pass == 0) {
@@ -1059,6 +1119,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                     const int i = lane + 64 * kk;
                     rBa[kk] = i < MP ? rB0[kk] - s.ba[i < MP ? i : 0] : 0.0;
                     rBb[kk] = i < MP ? s.bb[i < MP ? i : 0] : 0.0;
+                    rW[kk] = i < MP ? s.wgt[i < MP ? i : 0] : 1.0;
                 }
             } else {  // the dive: one bound of the (basic) branching variable moves
 #pragma unroll
@@ -1160,6 +1221,13 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                     const double ta = (sel_ba - la) * pinv, tb = (sel_bb - lb) * pinv;
                     const double elo = ev < n ? s.lo[ev < n ? ev : 0] : 0.0;
                     const double eup = ev < n ? s.up[ev < n ? ev : 0] : INF;
+                    // steepest-edge weights after the row operations of this pivot (tau came before C)
+                    const double wr = sel_w;
+                    double wrn = (wr * pinv) * pinv;
+                    wrn = wrn < 1.0 ? 1.0 : wrn;
+                    double tauv[PI];
+#pragma unroll
+                    for (int kk = 0; kk < PI; kk++) tauv[kk] = lane + 64 * kk < MP ? s.tau[lane + 64 * kk < MP ? lane + 64 * kk : 0] : 0.0;
                     MIPX_AWAIT_COL(NW * cols);
                     KPROF_MARK(4);
 #pragma unroll
@@ -1168,12 +1236,22 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                         const double a = i < MP ? s.alpha[i < MP ? i : 0] : 0.0;
                         const bool pr = i == r;
                         const double u0 = fma(-a, rhon, rB0[kk]), u1 = fma(-a, ta, rBa[kk]), u2 = fma(-a, tb, rBb[kk]);
+                        const double ratio = a * pinv;
+                        double wn = fma(ratio, fma(ratio, wr, -2.0 * tauv[kk]), rW[kk]);
+                        wn = wn < 1.0 ? 1.0 : wn;
                         rB0[kk] = pr ? rhon : u0;
                         rBa[kk] = pr ? vaq + ta : u1;
                         rBb[kk] = pr ? vbq + tb : u2;
+                        rW[kk] = pr ? wrn : wn;
                         rM[kk] = pr ? (ev << 2) : rM[kk];
                         rLo[kk] = pr ? elo : rLo[kk];
                         rUp[kk] = pr ? eup : rUp[kk];
+                    }
+                    if (++wage == kDseRefresh) {  // exact weights from the tableau after this pivot (A')
+                        wage = 0;
+                        __syncthreads();
+#pragma unroll
+                        for (int kk = 0; kk < PI; kk++) rW[kk] = lane + 64 * kk < MP ? s.wgt[lane + 64 * kk < MP ? lane + 64 * kk : 0] : 1.0;
                     }
                     MIPX_LEAVE_SELECT();
                 }
@@ -1194,6 +1272,19 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                 MIPX_EXTRACT_ROW(r);  // (b)
                 KPROF_MARK(1);
                 __syncthreads();  // B
+                // while the control wave runs the ratio test: tau_i = sum_j T_ij T_rj for the steepest-edge
+                // weights (the pivot row stays in registers for the sweep)
+                double rw[C];
+#pragma unroll
+                for (int jj = 0; jj < C; jj++) rw[jj] = s.row[MIPX_COL(jj)];
+                {
+                    double tq[R];
+                    MIPX_ROW_FOLD(MIPX_TERM_ROW, tq);
+                    if (cl == 0) {
+#pragma unroll
+                        for (int ii = 0; ii < R; ii++) s.tau[MIPX_ROW(ii)] = tq[ii];
+                    }
+                }
                 __syncthreads();  // C
                 KPROF_MARK(3);
                 int q, ev;
@@ -1204,7 +1295,12 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                 MIPX_PUBLISH_COL(q);  // (d)
                 pinv = 1.0 / uniform_f64(s.row[q]);  // 1/p: every wave works it out for itself
                 KPROF_MARK(4);
-                MIPX_UPDATE_T(r, q, pinv);
+                MIPX_UPDATE_T(r, q, pinv, MIPX_ROW_REG);
+                if (++wage == kDseRefresh) {  // the weights afresh from the tableau after this pivot
+                    wage = 0;
+                    MIPX_EXACT_WEIGHTS();
+                    __syncthreads();  // A'
+                }
                 KPROF_MARK(5);
                 __syncthreads();  // A
                 KPROF_MARK(0);
@@ -1232,6 +1328,8 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         atomicAdd(&g.prof[17], (unsigned long long)(npiv - iters));
         atomicAdd(&g.prof[18], 1ull);
     }
+    __syncthreads();
+    tprev = clock64();   // (the dump above is the profiler's own cost)
 #endif
     if (ctl) {
 #pragma unroll
@@ -1264,6 +1362,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     }
     for (int j = n + tid; j < NP; j += NT) s.key[j] = 0.0;
     __syncthreads();
+    KPROF_OUT_MARK(9);
     if (g.x)
         for (int j = tid; j < n; j += NT) g.x[onode * n + j] = s.key[j];
     if (g.y) {
@@ -1302,6 +1401,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
             didx[n + i] = s.bvar[i];
         }
     }
+    KPROF_OUT_MARK(10);
     double objv = 0.0;
     if (tid < 64) {
         // obj = fold-in-half sum of c_j x_j over the padded power-of-two length
@@ -1328,7 +1428,9 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         }
         objv = uniform_f64(sum);
     }
+    KPROF_OUT_MARK(12);
     __syncthreads();
+    KPROF_OUT_MARK(13);
     if (!DIVE || pass >= g.dive || !solve) break;  // (DIVE = false: the pass loop folds away)
 
     // ---- 5. dive: K4's branching rule on the solution in s.key, by the control wave -----------
@@ -1383,6 +1485,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         }
         if (lane == 0) s.dive_code = code;
     }
+    KPROF_OUT_MARK(14);
     __syncthreads();
     }
     if (__builtin_amdgcn_readfirstlane(s.dive_code) < 0) break;
@@ -1414,5 +1517,11 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
 #undef MIPX_ROW
 #undef MIPX_COL
 #undef MIPX_LEAVE_SELECT
+#undef MIPX_ROW_FOLD
+#undef MIPX_TERM_SQ
+#undef MIPX_TERM_ROW
+#undef MIPX_EXACT_WEIGHTS
+#undef MIPX_ROW_LDS
+#undef MIPX_ROW_REG
 
 }  // namespace mipx
