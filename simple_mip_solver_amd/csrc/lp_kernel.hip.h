@@ -1417,9 +1417,14 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
 #pragma unroll
             for (int k = 0; k < h; k++) p[k] = p[k] + p[k + h];
         }
+        // lane i < h adds lane i + h = i ^ h: the fold-in-half pairs, without an LDS round trip below 32
         double sum = p[0];
-#pragma unroll
-        for (int h = 32; h >= 1; h >>= 1) sum = sum + __shfl_down(sum, h, 64);
+        sum = sum + xor32_f64(sum);
+        sum = sum + swz16_f64(sum);
+        sum = sum + xor8_f64(sum);
+        sum = sum + xor4_f64(sum);
+        sum = sum + xor2_f64(sum);
+        sum = sum + xor1_f64(sum);
         if (tid == 0) {
             if (g.obj) g.obj[onode] = status == 1 ? INF : sum;
             if (g.status) g.status[onode] = status;
@@ -1437,7 +1442,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     if (ctl) {
         int code = -1;
         if (status == 0 && objv < g.dive_cutoff) {
-            double bk = -INF;
+            double bk = -1.0;
             int bp = kNoCand, nprobe = 0;
             // (candidates and their table entries were loaded at the start of the kernel)
 #pragma unroll
@@ -1448,11 +1453,12 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                 const double dist = fmin(v - fl, ce - v);
                 const bool frac = cv[kk] && dist > kVarEps;
                 const double key = g.rule == 0 ? dist : fmin(ccr[kk] * (ce - v), ccl[kk] * (v - fl));
-                keep(bk, bp, key, k, frac && che[kk]);
+                keep_max(bk, bp, key, k, frac && che[kk]);
                 nprobe += __popcll(__ballot(frac && !che[kk]));
             }
+            // (every key is >= +0: a distance to an integer, or a product of non-negative costs and distances)
             double km;
-            const int win = wave_argmax(bk, bp, km);
+            const int win = wave_argmax_pos(bk, bp, km);
             if (win != kNoCand && nprobe == 0) {
                 // the winner's variable, value and costs sit in lane win % 64, slot win / 64
                 const int wl = win & 63, wk = win >> 6;
