@@ -216,14 +216,15 @@ def highs_baseline(args, prob, A, b, c, sample):
 def time_to_optimal_leg(args, ctx, A, b, c, l, u, ints):
     """The metric's second leg on its own 256 x 128 instance.  Pure best-first finds no incumbent here
     in millions of nodes (round 1), the reference's depth-first node class does
-    (nodes/search/depth_first.py:16-28): depth-first in the engine, one-level dive on top."""
+    (nodes/search/depth_first.py:16-28): depth-first in the engine, the plunge (--dive levels) on top."""
     from simple_mip_solver_amd import _ffi
     p = _ffi.Problem(ctx, A, b, c)
     Bt = 1024
     t = _ffi.Tree(p, ints, l, u, branch_rule='pseudo cost', search_rule='depth first', max_batch=Bt,
                   pool_capacity=1 << 21)
     t.set_anchor_mode(True)
-    t.set_dive(max(1, args.dive))
+    depth = max(1, args.dive)
+    t.set_dive(depth)
     t0 = time.perf_counter()
     first, s = None, None
     while time.perf_counter() - t0 < args.tto_seconds:
@@ -234,7 +235,7 @@ def time_to_optimal_leg(args, ctx, A, b, c, l, u, ints):
             break
     el = time.perf_counter() - t0
     out = {'instance': f'{len(c)} vars x {len(b)} rows, seed {args.seed} (the metric\'s own instance)',
-           'search': f'PseudoCostBranchDepthFirstSearchNode semantics in the native engine, {Bt} nodes per step + one-level dive',
+           'search': f'PseudoCostBranchDepthFirstSearchNode semantics in the native engine, {Bt} nodes per step + in-place dive of depth {depth}',
            'time_to_first_incumbent': first, 'status': _ffi.TREE_STATUS[s['status']],
            'seconds': el, 'time_to_optimal': el if s['status'] == 1 else None,
            'primal_bound': None if s['primal_bound'] == float('inf') else s['primal_bound'],

@@ -377,7 +377,7 @@ int64_t mipx_tree_trace(mipx_tree *t, int64_t capacity, int64_t *node_id, int32_
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU: one process per GPU, open nodes sharded, a best-first queue per rank.
  * The reference is single-process (branch_and_bound.py:215-241): no counterpart.  The communicator
- * binds RCCL (xGMI) directly -- librccl.so is loaded on first use, PyTorch is not involved.
+ * binds RCCL (xGMI) directly -- librccl.so is loaded on first use, nothing else is needed.
  * ---------------------------------------------------------------------------------------- */
 typedef struct mipx_comm mipx_comm;
 /* Rank 0 makes the id (ncclGetUniqueId), the launcher hands its 128 bytes to every rank. */

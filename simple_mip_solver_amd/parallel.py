@@ -6,19 +6,20 @@ communicator (`Tree.set_comm`) and from then on `Tree.solve` is a collective cal
 exchange incumbent value + solution, shard dual bounds, open-node counts, stop flags, counters and
 pseudo-cost samples every few steps, decide termination together and move node records to a rank
 that runs dry -- all inside libmipx.so over RCCL / xGMI (csrc/comm.hip.h, csrc/tree_engine.hip.h).
-No ML framework involved: this module only finds out who the ranks are and hands rank 0's RCCL id to the others
-over a TCP socket.  The reference has no counterpart (single process).
+This module only finds out who the ranks are and hands rank 0's RCCL id to the others over a TCP
+socket.  The reference has no counterpart (single process).
 """
 import os
 import socket
 import time
 
 INF = float('inf')
-_ID_PORT_OFFSET = 23     # the id travels on MASTER_PORT + 23 (an elastic launcher's own store sits on MASTER_PORT)
+_ID_PORT_OFFSET = 23     # the id travels on MASTER_PORT + 23 (a launcher's own store sits on MASTER_PORT)
 
 
 def env_ranks():
-    """(rank, local_rank, world) as the launcher exports them (RANK, LOCAL_RANK, WORLD_SIZE: `bench.py --gpus N` or any elastic launcher); (0, 0, 1) without."""
+    """(rank, local_rank, world) as the launcher exports them (RANK, LOCAL_RANK, WORLD_SIZE:
+    `bench.py --gpus N` or any elastic launcher); (0, 0, 1) without."""
     return (int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')),
             int(os.environ.get('WORLD_SIZE', '1')))
 
