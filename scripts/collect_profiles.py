@@ -59,6 +59,16 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ groups (se
        "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024, "issue": issue}
 json.dump(out, open(O + '/pmc_latest.json', 'w'), indent=1)
 print(json.dumps(out)[:1500])
+with open(O + f'/{TAG}_pmc_hbm.csv', 'w') as fh:   # the per-dispatch values behind the two averages
+    fh.write('pass,kernel,grid,counter,value_KB\n')
+    for tag, name in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
+        rows = []
+        for f in sorted(glob.glob(O + f'/{tag}/*/*counter_collection.csv')):
+            for r in csv.DictReader(open(f)):
+                if r['Counter_Name'] == name and 'lp_dual_simplex<' in r['Kernel_Name'] and int(r['Grid_Size']) >= g // 4:
+                    rows.append((int(r.get('Dispatch_Id', 0)), r['Kernel_Name'][:60], r['Grid_Size'], float(r['Counter_Value'])))
+        for _, kn, gs, v in sorted(rows)[:16]:
+            fh.write(f'{tag},"{kn}",{gs},{name},{v:.6f}\n')
 # K1b
 st = by_grid(O + '/k1b_trace', O + f'/{TAG}_k1b_kernel_by_grid.csv')
 if st:
