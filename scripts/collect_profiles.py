@@ -5,16 +5,23 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = os.environ.get('PROFILE_TAG', 'r02')
 
 
+def newest(pattern):
+    """gpurun MERGES a call's files into gpurun_out/: passes of earlier calls may still lie beside the
+    latest one -- only the newest file of a pass counts."""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]
+
+
 def by_grid(trace_dir, out):
-    kt = glob.glob(trace_dir + '/*/*kernel_trace.csv')[0]
+    kt = newest(trace_dir + '/*/*kernel_trace.csv')[0]
     os.system(f'python3 {R}/scripts/summarize_profile.py {kt} > {out}')
-    st = glob.glob(trace_dir + '/*/*kernel_stats.csv')
+    st = newest(trace_dir + '/*/*kernel_stats.csv')
     return st[0] if st else None
 
 
 def counter(tag, name, kernel_substr):
     vals = collections.defaultdict(list)
-    for f in glob.glob(O + f'/{tag}/*/*counter_collection.csv'):
+    for f in newest(O + f'/{tag}/*/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] == name and kernel_substr in r['Kernel_Name']:
                 vals[int(r['Grid_Size'])].append(float(r['Counter_Value']))
@@ -36,7 +43,7 @@ _, w_kb = steady(wr)
 issue = {}
 for tag in ('sq1', 'sq2'):
     names = set()
-    for f in glob.glob(O + f'/{tag}/*/*counter_collection.csv'):
+    for f in newest(O + f'/{tag}/*/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             names.add(r['Counter_Name'])
     for nm in sorted(names):
@@ -63,7 +70,7 @@ with open(O + f'/{TAG}_pmc_hbm.csv', 'w') as fh:   # the per-dispatch values beh
     fh.write('pass,kernel,grid,counter,value_KB\n')
     for tag, name in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
         rows = []
-        for f in sorted(glob.glob(O + f'/{tag}/*/*counter_collection.csv')):
+        for f in newest(O + f'/{tag}/*/*counter_collection.csv'):
             for r in csv.DictReader(open(f)):
                 if r['Counter_Name'] == name and 'lp_dual_simplex<' in r['Kernel_Name'] and int(r['Grid_Size']) >= g // 4:
                     rows.append((int(r.get('Dispatch_Id', 0)), r['Kernel_Name'][:60], r['Grid_Size'], float(r['Counter_Value'])))

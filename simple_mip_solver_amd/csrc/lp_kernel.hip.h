@@ -119,12 +119,24 @@ constexpr int kDseRefresh = 64;   // iterations after which the steepest-edge we
 #define KPROF_MARK(k) do { } while (0)
 #endif
 // MIPX_KPROF_OUT: the slots of the refactorisation marks time the output section instead
-#ifdef MIPX_KPROF_OUT
+#if defined(MIPX_KPROF_RT)   /* ... or the stages of the ratio test (per iteration) */
+#define KPROF_REF_MARK(k) do { } while (0)
+#define KPROF_OUT_MARK(k) do { } while (0)
+#elif defined(MIPX_KPROF_OUT)
 #define KPROF_REF_MARK(k) do { } while (0)
 #define KPROF_OUT_MARK(k) KPROF_MARK(k)
 #else
 #define KPROF_REF_MARK(k) KPROF_MARK(k)
 #define KPROF_OUT_MARK(k) do { } while (0)
+#endif
+#ifdef MIPX_KPROF_RT
+#define KPROF_RT_MARK(k) KPROF_MARK(k)
+#define KPROF_RT_PIN_D(x) asm volatile("" ::"v"(x) : "memory")   /* the value is worked out before the mark */
+#define KPROF_RT_PIN_I(x) asm volatile("" ::"s"(x) : "memory")
+#else
+#define KPROF_RT_MARK(k) do { } while (0)
+#define KPROF_RT_PIN_D(x) do { } while (0)
+#define KPROF_RT_PIN_I(x) do { } while (0)
 #endif
 #ifdef MIPX_KPROF_SETUP
 #define KPROF_SETUP_MARK(k) KPROF_MARK(k)
@@ -513,6 +525,22 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
         }                                                                                   \
     } while (0)
 
+// control wave: what the ratio test needs of every column and does not depend on the pivot row
+#define MIPX_PREP_COLS()                                                                    \
+    do {                                                                                    \
+        const double tol_ = bland ? 0.0 : kDTol; /* Bland: the textbook ratio dj / |a| */   \
+        _Pragma("unroll") for (int kk = 0; kk < PJ; kk++) {                                 \
+            const int sd_ = cM[kk] & 3;                                                     \
+            dje[kk] = sd_ == 0 ? fmax(cD[kk], 0.0) : fmax(-cD[kk], 0.0);                    \
+            cN[kk] = dje[kk] + tol_;                                                        \
+            cS[kk] = sd_ == 0 ? 0x80000000u : 0u; /* at lower: eligible entries are negative */ \
+            cF[kk] = cM[kk] & 4;                                                            \
+            cP[kk] = ((cM[kk] >> 3) << 16) | (lane + 64 * kk);                              \
+            /* worked out HERE (the compiler would sink it to the uses behind the barrier) */ \
+            asm volatile("" : "+v"(dje[kk]), "+v"(cN[kk]), "+v"(cS[kk]), "+v"(cF[kk]), "+v"(cP[kk])); \
+        }                                                                                   \
+    } while (0)
+
 // Tableau waves: out_[ii] = fold-in-half sum over the padded columns of term_(ii, jj), valid at the
 // lanes with cl == 0.  Column j = 32*pp + 2*cl + e, so the levels of the canonical tree are pp (in the
 // thread, per e), then the column lanes cl + 8, 4, 2, 1 (DPP inside the 16-lane row group), then e.
@@ -615,8 +643,16 @@ _Pragma("unroll")                                                               
             double km;                                                                           \
             win = wave_argmax_pos(bk, blevel == lvl ? bp : kNoCand, km);                         \
         }                                                                                        \
-        if (cmd == 0) {                                                                          \
-            const int rr = win & 0x7fff, rl = rr & 63, rk = rr >> 6;                             \
+        /* the choice goes out at once; the border values of row r follow after barrier A */      \
+        sel_win = cmd == 0 ? (win & 0xffff) : (cmd << 16);                                       \
+        if (lane == 0) s.mbA.win = sel_win;                                                      \
+    } while (0)
+// ... and, after barrier A (the tableau waves are busy handing row r over): what the control wave itself
+// needs of the chosen row -- its border values, weight, the bound its variable leaves at
+#define MIPX_LEAVE_FETCH()                                                                   \
+    do {                                                                                     \
+        if (!(sel_win >> 16)) {                                                                  \
+            const int rr = sel_win & 0x7fff, rl = rr & 63, rk = rr >> 6;                         \
             double t0, t1, t2, t3, t4;                                                           \
             int tm;                                                                              \
             MIPX_PICK(t0, rLo, PI, rk);                                                          \
@@ -631,25 +667,13 @@ _Pragma("unroll")                                                               
             sel_bb = readlane_f64(t4, rl);                                                       \
             { double t5; MIPX_PICK(t5, rW, PI, rk); sel_w = readlane_f64(t5, rl); }              \
             const int lvv = __builtin_amdgcn_readlane(tm, rl) >> 2;                              \
-            double la_, lb_;                                                                     \
+            double la_;                                                                          \
             int newside;                                                                         \
-            if (!(win & 0x8000)) { la_ = lo; lb_ = 0.0; newside = 0; }                           \
-            else if (!isinf(up)) { la_ = up; lb_ = 0.0; newside = 1; }                           \
-            else { la_ = 0.0; lb_ = 1.0; newside = 2; }                                          \
-            (void)lb_;                                                                           \
-            sel_win = win & 0xffff;                                                              \
+            if (!(sel_win & 0x8000)) { la_ = lo; newside = 0; }                                  \
+            else if (!isinf(up)) { la_ = up; newside = 1; }                                      \
+            else { la_ = 0.0; newside = 2; }                                                     \
             sel_lvmeta = (lvv << 3) | newside | (lo == up ? 4 : 0);                              \
             sel_la = la_;                                                                        \
-            if (lane == 0) {                                                                     \
-                MailA mb_;                                                                       \
-                mb_.win = sel_win;                                                               \
-                mb_.lvmeta = sel_lvmeta;                                                         \
-                mb_.x = la_;                                                                     \
-                s.mbA = mb_;                                                                     \
-            }                                                                                    \
-        } else {                                                                                 \
-            sel_win = cmd << 16;                                                                 \
-            if (lane == 0) s.mbA.win = cmd << 16;                                                \
         }                                                                                        \
     } while (0)
 
@@ -1109,6 +1133,10 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
             int degen = 0;  // consecutive degenerate steps; > m+n -> Bland's rule
             const int nfk0 = nfake;
             int nfk = nfk0;
+            double dje[PJ], cN[PJ];  // per column, for the ratio test: max(+-d, 0), that + tol,
+            unsigned cS[PJ];         //   the sign mask of an eligible entry,
+            int cP[PJ];              //   the payload (variable << 16 | column)
+            int cF[PJ];              //   and "fixed: never enters" (nonzero)
             double sel_b0 = 0.0, sel_ba = 0.0, sel_bb = 0.0;  // border values of row r
             double sel_w = 1.0;                               //   and its steepest-edge weight
             int sel_win = 0, sel_lvmeta = 0;
@@ -1138,31 +1166,36 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
             for (;;) {
                 if (sel_win >> 16) { const int cmd = sel_win >> 16; status = cmd == 1 ? 0 : cmd == 3 ? 2 : 3; break; }
                 const int r = sel_win & 0x7fff;
-                const int lvmeta = sel_lvmeta;
-                const double la = sel_la, lb = (lvmeta & 3) == 2 ? 1.0 : 0.0;
                 const unsigned sflip = (sel_win & 0x8000) ? 0x80000000u : 0u;  // sigma = -1
+                MIPX_PREP_COLS();  // (while the tableau waves hand row r over)
                 KPROF_MARK(1);
                 __syncthreads();  // B: row r is in s.row
+                KPROF_RT_MARK(8);
                 // (c) Harris ratio test on row r
-                double aa[PJ], dje[PJ];
+                double aa[PJ];
                 bool el[PJ];
                 double k1 = INF;
                 int p1 = kNoCand;
-                const double tol = bland ? 0.0 : kDTol;  // Bland: the textbook ratio dj / |a|
+                // (per column, prepared while the last pivot's column was on its way: cS the sign that
+                // makes an eligible entry positive, cN = max(+-d, 0) + tol, cP the payload, cF "fixed")
 #pragma unroll
                 for (int kk = 0; kk < PJ; kk++) {
-                    const int j = lane + 64 * kk;
-                    const double rv = s.row[j];
-                    const double a = __hiloint2double(__double2hiint(rv) ^ sflip, __double2loint(rv));
-                    const int sd = cM[kk] & 3;
-                    el[kk] = ((cM[kk] & 4) == 0) & (sd == 0 ? (a < -kPivTol) : (a > kPivTol));
-                    dje[kk] = sd == 0 ? fmax(cD[kk], 0.0) : fmax(-cD[kk], 0.0);
+                    const double rv = s.row[lane + 64 * kk];
+                    const double a = __hiloint2double(__double2hiint(rv) ^ (sflip ^ cS[kk]), __double2loint(rv));
+                    el[kk] = (cF[kk] == 0) & (a > kPivTol);
                     aa[kk] = fabs(a);
-                    const double key = (dje[kk] + tol) / aa[kk];  // unconditionally: no divergent branch
-                    keep_min(k1, p1, key, ((cM[kk] >> 3) << 16) | j, el[kk]);
                 }
+                double key[PJ];  // the PJ divisions are independent chains: issued side by side
+#pragma unroll
+                for (int kk = 0; kk < PJ; kk++) key[kk] = cN[kk] / aa[kk];  // unconditionally: no divergent branch
+#pragma unroll
+                for (int kk = 0; kk < PJ; kk++) keep_min(k1, p1, key[kk], cP[kk], el[kk]);
+                KPROF_RT_PIN_D(k1); KPROF_RT_PIN_D(p1);
+                KPROF_RT_MARK(9);
                 double thmax;
                 const int w1 = wave_argmin_pos(k1, p1, thmax);
+                KPROF_RT_PIN_I(w1); KPROF_RT_PIN_D(thmax);
+                KPROF_RT_MARK(10);
                 int qq = -1;
                 if (w1 != kNoCand && bland) {
                     qq = w1 & 0xffff;  // ties -> lowest variable index
@@ -1174,14 +1207,30 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                     for (int kk = 0; kk < PJ; kk++) {
                         const int j = lane + 64 * kk;
                         const bool ok = el[kk] & ((j == jmin) | !(dje[kk] > thmax * aa[kk]));
-                        keep_max(k2, p2, aa[kk], ((cM[kk] >> 3) << 16) | j, ok);
+                        keep_max(k2, p2, aa[kk], cP[kk], ok);
                     }
+                    KPROF_RT_PIN_D(k2); KPROF_RT_PIN_D(p2);
+                    KPROF_RT_MARK(12);
                     double amax;
                     qq = wave_argmax_pos(k2, p2, amax) & 0xffff;
+                    KPROF_RT_PIN_I(qq);
+                    KPROF_RT_MARK(13);
                 }
-                double pinv = 0.0, vaq = 0.0, vbq = 0.0;
-                int ev = 0;
-                if (qq >= 0) {
+                if (lane == 0) s.mbB.q = qq;  // (the tableau waves want q and nothing else)
+                KPROF_RT_PIN_I(qq);
+                KPROF_RT_MARK(14);
+                KPROF_MARK(3);
+                __syncthreads();  // C: column chosen
+                if (qq < 0) { status = 1; break; }  // no entering column: primal infeasible
+                const int q = qq;
+                // the rest of the leaving row's data and the bookkeeping of the choice, while the tableau
+                // waves get column q out
+                MIPX_LEAVE_FETCH();
+                const int lvmeta = sel_lvmeta;
+                const double la = sel_la, lb = (lvmeta & 3) == 2 ? 1.0 : 0.0;
+                int ev;
+                double vaq, vbq;
+                {
                     const int ql = qq & 63, qk = qq >> 6;
                     double t0;
                     int tm;
@@ -1193,23 +1242,10 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                     bland = degen > m + n;
                     nfk += ((lvmeta & 3) == 2 ? 1 : 0) - ((cm & 3) == 2 ? 1 : 0);
                     ev = cm >> 3;
-                    if (lane == 0) {
-                        MailB mb;
-                        mb.q = qq;
-                        mb.ev = ev;
-                        mb.pinv = 0.0;
-                        s.mbB = mb;
-                    }
                     vaq = uniform_f64(s.va[qq]);
                     vbq = uniform_f64(s.vb[qq]);
-                } else if (lane == 0) {
-                    s.mbB.q = -1;
                 }
-                KPROF_MARK(3);
-                __syncthreads();  // C: column chosen
-                if (qq < 0) { status = 1; break; }  // no entering column: primal infeasible
-                const int q = qq;
-                pinv = 1.0 / uniform_f64(s.row[q]);  // 1/p: every wave works it out for itself
+                const double pinv = 1.0 / uniform_f64(s.row[q]);  // 1/p: every wave works it out for itself
                 iters++;
                 npiv++;
                 cols++;
@@ -1517,12 +1553,14 @@ __global__ __launch_bounds__(64 * (NW + 1)) void lp_dual_simplex(LpArgs g) {
 #undef MIPX_EXTRACT_ROW
 #undef MIPX_UPDATE_T
 #undef MIPX_UPDATE_COLS
+#undef MIPX_PREP_COLS
 #undef MIPX_PICK
 #undef MIPX_ROWSUMS
 #undef MIPX_ROWSUM_STEP
 #undef MIPX_ROW
 #undef MIPX_COL
 #undef MIPX_LEAVE_SELECT
+#undef MIPX_LEAVE_FETCH
 #undef MIPX_ROW_FOLD
 #undef MIPX_TERM_SQ
 #undef MIPX_TERM_ROW

@@ -132,6 +132,10 @@ int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t strea
                     h[9] / rf, h[10] / rf, h[12] / rf, h[13] / rf, h[14] / rf,
                     (h[9] + h[10] + h[12] + h[13] + h[14]) / rf, h[15] / lps, h[8] / it, h[11] / it,
                     h[7] / lps, h[6] / lps);
+#ifdef MIPX_KPROF_RT
+            fprintf(stderr, "  ratio test cycles/iter: wait at B %.0f pass1 %.0f argmin %.0f pass2 %.0f argmax %.0f tail %.0f  (m3 = the barrier C)\n",
+                    h[8] / it, h[9] / it, h[10] / it, h[12] / it, h[13] / it, h[14] / it);
+#endif
         }
         return MIPX_OK;
 #else
