@@ -26,6 +26,7 @@
 //     -ffp-contract=off, following the canonical operation order documented in
 //     oracle/mipx_oracle.c so results are bit-identical to the CPU oracle.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -418,6 +419,12 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
         dst_ = arr_[0];                                                                     \
         _Pragma("unroll") for (int t_ = 1; t_ < n_; t_++) dst_ = (k_) == t_ ? arr_[t_] : dst_; \
     } while (0)
+template <int C>
+struct RowArr {
+    double v[C];
+    __device__ __forceinline__ double &operator[](int j) { return v[j]; }
+    __device__ __forceinline__ const double &operator[](int j) const { return v[j]; }
+};
 // row / column of a tableau lane's element (ii, jj)
 #define MIPX_ROW(ii_) (grp + NG * (ii_))
 #define MIPX_COL(jj_) (32 * ((jj_) >> 1) + 2 * cl + ((jj_)&1))
@@ -428,8 +435,12 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
     do {                                                                                    \
         const int qjj_ = 2 * ((q_) >> 5) + ((q_)&1);                                        \
         if (cl == (((q_)&31) >> 1)) {                                                       \
-            _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == qjj_) {              \
-                _Pragma("unroll") for (int ii = 0; ii < R; ii++) s.alpha[MIPX_ROW(ii)] = T[ii][jj]; \
+            if constexpr (kVecT) {                                                          \
+                _Pragma("unroll") for (int ii = 0; ii < R; ii++) s.alpha[MIPX_ROW(ii)] = T[ii][qjj_]; \
+            } else {                                                                        \
+                _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == qjj_) {          \
+                    _Pragma("unroll") for (int ii = 0; ii < R; ii++) s.alpha[MIPX_ROW(ii)] = T[ii][jj]; \
+                }                                                                           \
             }                                                                               \
         }                                                                                   \
         /* the count first: the control wave is waiting for it.  (The release orders the stores */ \
@@ -472,8 +483,12 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
                 T[ii][jj] = fma(-al[ii], rh[jj], T[ii][jj]);                                \
         }                                                                                   \
         if (cl == qcl_) { /* column q <- -alpha * (1/p) */                                  \
-            _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == qjj_) {              \
-                _Pragma("unroll") for (int ii = 0; ii < R; ii++) T[ii][jj] = -al[ii] * (pinv_); \
+            if constexpr (kVecT) {                                                          \
+                _Pragma("unroll") for (int ii = 0; ii < R; ii++) T[ii][qjj_] = -al[ii] * (pinv_); \
+            } else {                                                                        \
+                _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == qjj_) {          \
+                    _Pragma("unroll") for (int ii = 0; ii < R; ii++) T[ii][jj] = -al[ii] * (pinv_); \
+                }                                                                           \
             }                                                                               \
         }                                                                                   \
         if (grp == rg_) { /* row r <- row * (1/p), and 1/p at the pivot position */         \
@@ -493,10 +508,17 @@ __device__ __forceinline__ void read_mail(const MailB &mb, int &q, int &ev, doub
         const int qnjj_ = 2 * ((qn_) >> 5) + ((qn_)&1);                                     \
         const double rhn_ = s.row[qn_] * (pinv_);                                           \
         if (cl == (((qn_)&31) >> 1)) {                                                      \
-            _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == qnjj_) {             \
+            if constexpr (kVecT) {                                                          \
                 _Pragma("unroll") for (int ii = 0; ii < R; ii++) {                          \
-                    const double v_ = fma(-al[ii], rhn_, T[ii][jj]);                        \
+                    const double v_ = fma(-al[ii], rhn_, T[ii][qnjj_]);                     \
                     s.alpha[MIPX_ROW(ii)] = (grp == rg_ && ii == rl_) ? rhn_ : v_;          \
+                }                                                                           \
+            } else {                                                                        \
+                _Pragma("unroll") for (int jj = 0; jj < C; jj++) if (jj == qnjj_) {         \
+                    _Pragma("unroll") for (int ii = 0; ii < R; ii++) {                      \
+                        const double v_ = fma(-al[ii], rhn_, T[ii][jj]);                    \
+                        s.alpha[MIPX_ROW(ii)] = (grp == rg_ && ii == rl_) ? rhn_ : v_;      \
+                    }                                                                       \
                 }                                                                           \
             }                                                                               \
         }                                                                                   \
@@ -722,7 +744,13 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     if (tid < 16) s.prof[tid] = 0;
     unsigned long long tprev = clock64();
 #endif
-    double T[R][C];  // tableau waves: T[ii][jj] = tableau[grp + NG*ii][32*(jj/2) + 2*cl + jj%2]
+    // A lane's part of a tableau row is a C-vector where the register file has room for the tuples:
+    // the entry of a wave-uniform column then comes out by GPR indexing (s_set_gpr_idx) instead of a
+    // ladder of C uniform branches.  Only where the ladder is long and the tuples fit: the 192-row tile
+    // keeps plain arrays (it spills less with them), the small tiles their 4- and 8-way ladders.
+    constexpr bool kVecT = C >= 16 && R * C <= 96;
+    typedef double TVec __attribute__((ext_vector_type(C)));
+    typename std::conditional<kVecT, TVec, RowArr<C>>::type T[R];  // tableau waves: T[ii][jj] = tableau[grp + NG*ii][32*(jj/2) + 2*cl + jj%2]
     double al[R];    // tableau waves: their part of the current pivot column
     // control wave: column border (column j = lane + 64*kk) and row border (row i = lane + 64*kk)
     double cD[PJ];   // reduced cost
@@ -1161,16 +1189,22 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                     else s.lo[dvar] = dbound;
                 }
             }
+            // Where the hand-overs of the large tiles leave the control wave idle, work that does not
+            // depend on the row / column just chosen is placed in their shadow; the small tiles' hand-overs
+            // are too short for that (same arithmetic either way).
+            constexpr bool kShadow = NW >= 7;
             MIPX_LEAVE_SELECT();
+            if constexpr (!kShadow) MIPX_LEAVE_FETCH();
             __syncthreads();  // A
             for (;;) {
                 if (sel_win >> 16) { const int cmd = sel_win >> 16; status = cmd == 1 ? 0 : cmd == 3 ? 2 : 3; break; }
                 const int r = sel_win & 0x7fff;
                 const unsigned sflip = (sel_win & 0x8000) ? 0x80000000u : 0u;  // sigma = -1
-                MIPX_PREP_COLS();  // (while the tableau waves hand row r over)
+                if constexpr (kShadow) MIPX_PREP_COLS();  // (while the tableau waves hand row r over)
                 KPROF_MARK(1);
                 __syncthreads();  // B: row r is in s.row
                 KPROF_RT_MARK(8);
+                if constexpr (!kShadow) MIPX_PREP_COLS();
                 // (c) Harris ratio test on row r
                 double aa[PJ];
                 bool el[PJ];
@@ -1225,7 +1259,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                 const int q = qq;
                 // the rest of the leaving row's data and the bookkeeping of the choice, while the tableau
                 // waves get column q out
-                MIPX_LEAVE_FETCH();
+                if constexpr (kShadow) MIPX_LEAVE_FETCH();
                 const int lvmeta = sel_lvmeta;
                 const double la = sel_la, lb = (lvmeta & 3) == 2 ? 1.0 : 0.0;
                 int ev;
@@ -1290,6 +1324,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                         for (int kk = 0; kk < PI; kk++) rW[kk] = lane + 64 * kk < MP ? s.wgt[lane + 64 * kk < MP ? lane + 64 * kk : 0] : 1.0;
                     }
                     MIPX_LEAVE_SELECT();
+                    if constexpr (!kShadow) MIPX_LEAVE_FETCH();
                 }
                 KPROF_MARK(5);
                 __syncthreads();  // A: row chosen
