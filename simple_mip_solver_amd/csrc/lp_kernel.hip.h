@@ -696,6 +696,8 @@ _Pragma("unroll")                                                               
             else { la_ = 0.0; newside = 2; }                                                     \
             sel_lvmeta = (lvv << 3) | newside | (lo == up ? 4 : 0);                              \
             sel_la = la_;                                                                        \
+            /* (worked out HERE: the compiler would sink it to the uses behind the barriers) */  \
+            asm volatile("" : "+s"(sel_b0), "+s"(sel_ba), "+s"(sel_bb), "+s"(sel_w), "+s"(sel_la), "+s"(sel_lvmeta)); \
         }                                                                                        \
     } while (0)
 
@@ -1200,7 +1202,10 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                 if (sel_win >> 16) { const int cmd = sel_win >> 16; status = cmd == 1 ? 0 : cmd == 3 ? 2 : 3; break; }
                 const int r = sel_win & 0x7fff;
                 const unsigned sflip = (sel_win & 0x8000) ? 0x80000000u : 0u;  // sigma = -1
-                if constexpr (kShadow) MIPX_PREP_COLS();  // (while the tableau waves hand row r over)
+                if constexpr (kShadow) {  // (while the tableau waves hand row r over)
+                    MIPX_LEAVE_FETCH();
+                    MIPX_PREP_COLS();
+                }
                 KPROF_MARK(1);
                 __syncthreads();  // B: row r is in s.row
                 KPROF_RT_MARK(8);
@@ -1257,9 +1262,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                 __syncthreads();  // C: column chosen
                 if (qq < 0) { status = 1; break; }  // no entering column: primal infeasible
                 const int q = qq;
-                // the rest of the leaving row's data and the bookkeeping of the choice, while the tableau
-                // waves get column q out
-                if constexpr (kShadow) MIPX_LEAVE_FETCH();
+                // the bookkeeping of the choice, while the tableau waves get column q out
                 const int lvmeta = sel_lvmeta;
                 const double la = sel_la, lb = (lvmeta & 3) == 2 ? 1.0 : 0.0;
                 int ev;
@@ -1284,11 +1287,14 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                 npiv++;
                 cols++;
                 MIPX_UPDATE_COLS(q, pinv, lvmeta);
+                // (worked out HERE, while column q is on its way: the compiler would sink it behind the wait)
+#pragma unroll
+                for (int kk = 0; kk < PJ; kk++) asm volatile("" : "+v"(cD[kk]), "+v"(cM[kk]));
                 if (lane == 0) { s.va[q] = la; s.vb[q] = lb; }
                 KPROF_MARK(2);
                 {   // basic values after the pivot on (r, q), then the next leaving row
-                    const double rhon = sel_b0 * pinv;
-                    const double ta = (sel_ba - la) * pinv, tb = (sel_bb - lb) * pinv;
+                    double rhon = sel_b0 * pinv;
+                    double ta = (sel_ba - la) * pinv, tb = (sel_bb - lb) * pinv;
                     const double elo = ev < n ? s.lo[ev < n ? ev : 0] : 0.0;
                     const double eup = ev < n ? s.up[ev < n ? ev : 0] : INF;
                     // steepest-edge weights after the row operations of this pivot (tau came before C)
@@ -1298,6 +1304,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                     double tauv[PI];
 #pragma unroll
                     for (int kk = 0; kk < PI; kk++) tauv[kk] = lane + 64 * kk < MP ? s.tau[lane + 64 * kk < MP ? lane + 64 * kk : 0] : 0.0;
+                    asm volatile("" : "+v"(rhon), "+v"(ta), "+v"(tb), "+v"(wrn));
                     MIPX_AWAIT_COL(NW * cols);
                     KPROF_MARK(4);
 #pragma unroll
