@@ -51,3 +51,10 @@ for rep in range(3):
         rep, ms, B / ms * 1e3, it.mean(), npv.mean(), ms * 1e3 * 256 / piv, np.bincount(st, minlength=4)))
 bytes_per_pivot = 2 * 8 * (m + 1) * (n + m + 1)
 print('algorithmic GB/s %.1f' % (piv * bytes_per_pivot / (ms * 1e-3) / 1e9))
+# the same batch through the host-buffer entry point (mipx_lp_solve_batch: PCIe copies + read-back inside)
+for rep in range(3):
+    t0 = time.perf_counter()
+    h = p.solve_batch(L2, U2, V2)
+    dt = time.perf_counter() - t0
+    print('host buffers rep %d: %.3f ms wall -> %.0f LP/s (PCIe inclusive; %.1f KB in + %.1f KB out per LP)' % (
+        rep, dt * 1e3, B / dt, (2 * n * 8 + n + m) / 1e3, (n * 8 + m * 8 + n + m + 20) / 1e3))
