@@ -387,6 +387,7 @@ struct Smem {
     int wlist[NP];      // columns of the variables the warm start wants basic, ascending variable
     int nw;
     int nfake0;
+    double objv;        // objective of the LP just solved (worked out by tableau wave 0 for the control wave)
     int dive_code;      // branching variable of the in-place dive, -1: none
     int seq;            // pivot column parts published so far (one count per tableau wave and column)
     int pos[NP + MP];   // column of each variable in the starting tableau, -1 if basic
@@ -1410,33 +1411,28 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     tprev = clock64();   // (the dump above is the profiler's own cost)
 #endif
     if (ctl) {
+        // the borders go to LDS for the output loops; x by variable index (s.key) straight from the registers
 #pragma unroll
         for (int kk = 0; kk < PJ; kk++) {
             const int j = lane + 64 * kk;
+            const int v = cM[kk] >> 3, sd = cM[kk] & 3;
             s.d[j] = cD[kk];
-            s.nvar[j] = cM[kk] >> 3;
-            s.side[j] = cM[kk] & 3;
+            s.nvar[j] = v;
+            s.side[j] = sd;
+            if (j < n && v < n) s.key[v] = sd == 2 ? kMReport : s.va[j];
         }
 #pragma unroll
         for (int kk = 0; kk < PI; kk++) {
             const int i = lane + 64 * kk;
             if (i < MP) {
+                const int v = rM[kk] >> 2;
                 s.beta0[i] = rB0[kk];
                 s.ba[i] = rBa[kk];
                 s.bb[i] = rBb[kk];
-                s.bvar[i] = rM[kk] >> 2;
+                s.bvar[i] = v;
+                if (i < m && v < n) s.key[v] = fma(rBb[kk], kMReport, rBa[kk]);
             }
         }
-    }
-    __syncthreads();
-    // assemble x by variable index in s.key
-    for (int j = tid; j < n; j += NT) {
-        const int v = s.nvar[j];
-        if (v < n) s.key[v] = s.side[j] == 2 ? kMReport : s.va[j];
-    }
-    for (int i = tid; i < m; i += NT) {
-        const int v = s.bvar[i];
-        if (v < n) s.key[v] = fma(s.bb[i], kMReport, s.ba[i]);
     }
     for (int j = n + tid; j < NP; j += NT) s.key[j] = 0.0;
     __syncthreads();
@@ -1480,8 +1476,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         }
     }
     KPROF_OUT_MARK(10);
-    double objv = 0.0;
-    if (tid < 64) {
+    if (!ctl && tw == 0) {
         // obj = fold-in-half sum of c_j x_j over the padded power-of-two length
         constexpr int PER = NP / 64;
         double p[PER];
@@ -1503,72 +1498,75 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
         sum = sum + xor4_f64(sum);
         sum = sum + xor2_f64(sum);
         sum = sum + xor1_f64(sum);
-        if (tid == 0) {
-            if (g.obj) g.obj[onode] = status == 1 ? INF : sum;
-            if (g.status) g.status[onode] = status;
-            if (g.iters) g.iters[onode] = iters;
-            if (g.npivots) g.npivots[onode] = npiv;
+        if (lane == 0) s.objv = sum;
+    }
+    // ---- 5. dive: K4's branching rule on the solution in s.key, by the control wave, meanwhile; whether
+    // the node may dive at all (optimal, below the cutoff) is settled behind the barrier ----------------
+    const bool more = DIVE && pass < g.dive && solve;  // (DIVE = false: the pass loop folds away)
+    int code = -1;
+    double dval = 0.0;
+    if (ctl && more && status == 0) {
+        double bk = -1.0;
+        int bp = kNoCand, nprobe = 0;
+        // (candidates and their table entries were loaded at the start of the kernel)
+#pragma unroll
+        for (int kk = 0; kk < PJ; kk++) {
+            const int k = lane + 64 * kk;
+            const double v = s.key[ci[kk]];
+            const double fl = floor(v), ce = ceil(v);
+            const double dist = fmin(v - fl, ce - v);
+            const bool frac = cv[kk] && dist > kVarEps;
+            const double key = g.rule == 0 ? dist : fmin(ccr[kk] * (ce - v), ccl[kk] * (v - fl));
+            keep_max(bk, bp, key, k, frac && che[kk]);
+            nprobe += __popcll(__ballot(frac && !che[kk]));
         }
-        objv = uniform_f64(sum);
+        // (every key is >= +0: a distance to an integer, or a product of non-negative costs and distances)
+        double km;
+        const int win = wave_argmax_pos(bk, bp, km);
+        if (win != kNoCand && nprobe == 0) {
+            // the winner's variable, value and costs sit in lane win % 64, slot win / 64
+            const int wl = win & 63, wk = win >> 6;
+            int t_i;
+            double t_l, t_r;
+            MIPX_PICK(t_i, ci, PJ, wk);
+            MIPX_PICK(t_l, ccl, PJ, wk);
+            MIPX_PICK(t_r, ccr, PJ, wk);
+            dvar = __builtin_amdgcn_readlane(t_i, wl);
+            const double wcl = readlane_f64(t_l, wl), wcr = readlane_f64(t_r, wl);
+            const double v = uniform_f64(s.key[dvar]);
+            const double fl = floor(v), ce = ceil(v);
+            // towards the side the rule expects to cost less (most fractional: the nearer one)
+            if (g.rule == 0) ddir = (v - fl <= ce - v) ? 0 : 1;
+            else ddir = (wcl * (v - fl) <= wcr * (ce - v)) ? 0 : 1;
+            dbound = ddir == 0 ? fl : ce;
+            dval = v;
+            bool mine = false;  // a bound change in place needs the variable basic
+#pragma unroll
+            for (int kk = 0; kk < PI; kk++) mine |= (lane + 64 * kk < m) && (rM[kk] >> 2) == dvar;
+            if (__ballot(mine) != 0ull) code = dvar;
+        }
     }
     KPROF_OUT_MARK(12);
     __syncthreads();
     KPROF_OUT_MARK(13);
-    if (!DIVE || pass >= g.dive || !solve) break;  // (DIVE = false: the pass loop folds away)
-
-    // ---- 5. dive: K4's branching rule on the solution in s.key, by the control wave -----------
     if (ctl) {
-        int code = -1;
-        if (status == 0 && objv < g.dive_cutoff) {
-            double bk = -1.0;
-            int bp = kNoCand, nprobe = 0;
-            // (candidates and their table entries were loaded at the start of the kernel)
-#pragma unroll
-            for (int kk = 0; kk < PJ; kk++) {
-                const int k = lane + 64 * kk;
-                const double v = s.key[ci[kk]];
-                const double fl = floor(v), ce = ceil(v);
-                const double dist = fmin(v - fl, ce - v);
-                const bool frac = cv[kk] && dist > kVarEps;
-                const double key = g.rule == 0 ? dist : fmin(ccr[kk] * (ce - v), ccl[kk] * (v - fl));
-                keep_max(bk, bp, key, k, frac && che[kk]);
-                nprobe += __popcll(__ballot(frac && !che[kk]));
+        const double objv = uniform_f64(s.objv);
+        if (!(status == 0 && objv < g.dive_cutoff)) code = -1;
+        if (lane == 0) {
+            if (g.obj) g.obj[onode] = status == 1 ? INF : objv;
+            if (g.status) g.status[onode] = status;
+            if (g.iters) g.iters[onode] = iters;
+            if (g.npivots) g.npivots[onode] = npiv;
+            if (code >= 0) {
+                const size_t di = (size_t)pass * (size_t)g.dive_off + node;
+                g.dive_var[di] = dvar;
+                g.dive_dir[di] = ddir;
+                g.dive_val[di] = dval;
             }
-            // (every key is >= +0: a distance to an integer, or a product of non-negative costs and distances)
-            double km;
-            const int win = wave_argmax_pos(bk, bp, km);
-            if (win != kNoCand && nprobe == 0) {
-                // the winner's variable, value and costs sit in lane win % 64, slot win / 64
-                const int wl = win & 63, wk = win >> 6;
-                int t_i;
-                double t_l, t_r;
-                MIPX_PICK(t_i, ci, PJ, wk);
-                MIPX_PICK(t_l, ccl, PJ, wk);
-                MIPX_PICK(t_r, ccr, PJ, wk);
-                dvar = __builtin_amdgcn_readlane(t_i, wl);
-                const double wcl = readlane_f64(t_l, wl), wcr = readlane_f64(t_r, wl);
-                const double v = uniform_f64(s.key[dvar]);
-                const double fl = floor(v), ce = ceil(v);
-                // towards the side the rule expects to cost less (most fractional: the nearer one)
-                if (g.rule == 0) ddir = (v - fl <= ce - v) ? 0 : 1;
-                else ddir = (wcl * (v - fl) <= wcr * (ce - v)) ? 0 : 1;
-                dbound = ddir == 0 ? fl : ce;
-                bool mine = false;  // a bound change in place needs the variable basic
-#pragma unroll
-                for (int kk = 0; kk < PI; kk++) mine |= (lane + 64 * kk < m) && (rM[kk] >> 2) == dvar;
-                if (__ballot(mine) != 0ull) {
-                    code = dvar;
-                    if (lane == 0) {
-                        const size_t di = (size_t)pass * (size_t)g.dive_off + node;
-                        g.dive_var[di] = dvar;
-                        g.dive_dir[di] = ddir;
-                        g.dive_val[di] = v;
-                    }
-                }
-            }
+            s.dive_code = code;
         }
-        if (lane == 0) s.dive_code = code;
     }
+    if (!more) break;
     KPROF_OUT_MARK(14);
     __syncthreads();
     }
