@@ -211,7 +211,8 @@ struct StepBuf {
     // list, the row duals, the loop's state and the pool of candidate cuts (a slab of slab_rows rows)
     int32_t *w_ncut = nullptr, *w_ids = nullptr, *cs_state = nullptr, *cs_active = nullptr,
             *cs_resolve = nullptr, *cs_counters = nullptr, *k2_ncuts = nullptr, *k3_nadded = nullptr,
-            *k3_added = nullptr, *k3_term = nullptr, *pool_list = nullptr, *dump_idx = nullptr;
+            *k3_added = nullptr, *k3_term = nullptr, *pool_list = nullptr, *dump_idx = nullptr,
+            *cs_need_tab = nullptr;
     double *d_y = nullptr, *cs_before = nullptr, *slab_pi = nullptr, *slab_pi0 = nullptr,
            *dump_T = nullptr, *dump_vec = nullptr;
     int32_t *h_cs = nullptr;   // pinned: [counters (4) | state fields 0..6 + w_ncut (8 x max_batch)]
@@ -570,6 +571,9 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
         for (int k = 0; k < B; k++) maxc = std::max(maxc, (int)S.recs[(size_t)k].ncut);
         CutLaunch cl;
         cl.ncut = S.w_ncut; cl.ids = S.w_ids; cl.y = S.d_y; cl.m_rows = t->m + maxc;
+        if (t->cp.exact_tableau == 0) {   // the tableau the solve ends with is the first round's (K2's input)
+            cl.dT = S.dump_T; cl.dvec = S.dump_vec; cl.didx = S.dump_idx;
+        }
         HIP_TRY(ctx, hipEventRecord(S.e0, st));
         rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, S.d_slot, 0, S.d_status, S.d_obj, S.d_x,
                        S.d_vout, S.d_iters, S.d_npiv, nullptr, nullptr, nullptr, &cl);
@@ -607,8 +611,13 @@ int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
     const size_t MB = (size_t)t->max_batch;
     int maxc = 0;
     for (int k = 0; k < B; k++) maxc = std::max(maxc, (int)S.recs[(size_t)k].ncut);
+    // Without exact_tableau every LP launch of the loop dumps the tableau it ends with, and K2 reads that:
+    // a launch of its own for the tableau only where a round starts by removing rows.  (exact_tableau:
+    // the tableau is refactored from the slack basis like the per-node path's, always by its own launch.)
+    const bool fused = t->cp.exact_tableau == 0;
     for (int round = 0;; round++) {
         HIP_TRY(ctx, hipMemsetAsync(S.cs_counters, 0, 8, st));   // n_active, n_changed (max_ncut stays)
+        HIP_TRY(ctx, hipMemsetAsync(S.cs_counters + 3, 0, 4, st));   // n_need_tab
         mipx::CutRoundArgs ra;
         ra.n = n; ra.m0 = t->m; ra.mstride = t->mrows; ra.kc = t->kc; ra.batch = B; ra.round = round;
         ra.max_rounds = t->cp.max_cut_generation_iterations;
@@ -616,6 +625,7 @@ int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
         ra.status = S.d_status; ra.obj = S.d_obj; ra.mipf = S.d_mipf; ra.y = S.d_y; ra.vstat = S.d_vout;
         ra.ncut = S.w_ncut; ra.ids = S.w_ids; ra.state = S.cs_state; ra.obj_before = S.cs_before;
         ra.active = S.cs_active; ra.resolve = S.cs_resolve; ra.counters = S.cs_counters;
+        ra.have_dump = fused ? 1 : 0; ra.need_tab = S.cs_need_tab;
         hipLaunchKernelGGL(mipx::cut_round_begin, dim3(B), dim3(64), 0, st, ra);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemcpyAsync(S.h_cs, S.cs_counters, 16, hipMemcpyDeviceToHost, st));
@@ -624,13 +634,16 @@ int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
         // the tableau of every generating node's basis (refactorisation from the slack basis -- or,
         // without exact_tableau, from the root's anchor where the node has no cut rows -- then zero
         // iterations: the basis is optimal), dumped for K2
-        CutLaunch cl;
-        cl.ncut = S.w_ncut; cl.ids = S.w_ids; cl.vstat_by_node = 1; cl.active = S.cs_active;
-        cl.m_rows = t->m + maxc; cl.dT = S.dump_T; cl.dvec = S.dump_vec; cl.didx = S.dump_idx;
-        cl.no_anchor = t->cp.exact_tableau != 0;
-        int rc = launch_lp(t, B, t->pool_l, t->pool_u, S.d_vout, S.d_slot, 0, nullptr, nullptr, nullptr,
+        int rc = MIPX_OK;
+        if (S.h_cs[3] > 0) {
+            CutLaunch cl;
+            cl.ncut = S.w_ncut; cl.ids = S.w_ids; cl.vstat_by_node = 1; cl.active = S.cs_need_tab;
+            cl.m_rows = t->m + maxc; cl.dT = S.dump_T; cl.dvec = S.dump_vec; cl.didx = S.dump_idx;
+            cl.no_anchor = t->cp.exact_tableau != 0;
+            rc = launch_lp(t, B, t->pool_l, t->pool_u, S.d_vout, S.d_slot, 0, nullptr, nullptr, nullptr,
                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &cl);
-        if (rc) return rc;
+            if (rc) return rc;
+        }
         mipx::GomoryArgs ga;
         ga.m = t->m; ga.n = n; ga.batch = B;
         ga.A = t->prob->dA; ga.b = t->prob->db;
@@ -681,6 +694,7 @@ int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
             CutLaunch rl;
             rl.ncut = S.w_ncut; rl.ids = S.w_ids; rl.vstat_by_node = 1; rl.active = S.cs_resolve;
             rl.y = S.d_y; rl.m_rows = t->m + maxc;
+            if (fused) { rl.dT = S.dump_T; rl.dvec = S.dump_vec; rl.didx = S.dump_idx; }
             rl.no_anchor = true;   // (a node that changed rows has, or just had, cut rows)
             rc = launch_lp(t, B, t->pool_l, t->pool_u, S.d_vout, S.d_slot, 0, S.d_status, S.d_obj, S.d_x,
                            S.d_vout, S.d_iters, S.d_npiv, nullptr, nullptr, nullptr, &rl);
@@ -1415,6 +1429,7 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
             rc |= dmalloc(ctx, &S.w_ncut, B); rc |= dmalloc(ctx, &S.w_ids, B * K);
             rc |= dmalloc(ctx, &S.cs_state, (size_t)mipx::CF_FIELDS * B);
             rc |= dmalloc(ctx, &S.cs_active, B); rc |= dmalloc(ctx, &S.cs_resolve, B);
+            rc |= dmalloc(ctx, &S.cs_need_tab, B);
             rc |= dmalloc(ctx, &S.cs_counters, 4); rc |= dmalloc(ctx, &S.k2_ncuts, B);
             rc |= dmalloc(ctx, &S.k3_nadded, B); rc |= dmalloc(ctx, &S.k3_added, B * SR);
             rc |= dmalloc(ctx, &S.k3_term, B); rc |= dmalloc(ctx, &S.pool_list, B * SR);
@@ -1509,7 +1524,7 @@ void mipx_tree_destroy(mipx_tree *t) {
     for (StepBuf &S : t->buf) {
         void *sp[] = {S.w_ncut, S.w_ids, S.cs_state, S.cs_active, S.cs_resolve, S.cs_counters, S.k2_ncuts, S.k3_nadded,
                       S.k3_added, S.k3_term, S.pool_list, S.d_y, S.cs_before, S.slab_pi, S.slab_pi0, S.dump_T, S.dump_vec,
-                      S.dump_idx};
+                      S.dump_idx, S.cs_need_tab};
         for (void *q : sp)
             if (q) (void)hipFree(q);
         if (S.h_cs) (void)hipHostFree(S.h_cs);

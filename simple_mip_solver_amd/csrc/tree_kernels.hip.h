@@ -234,7 +234,12 @@ struct CutRoundArgs {
     double *obj_before;            // batch
     int32_t *active;               // batch: in/out (still generating this round)
     int32_t *resolve;              // batch: out, 1 where a cut was removed (the LP changed)
-    int32_t *counters;             // [n_active, n_changed, max_ncut, -]
+    int32_t *counters;             // [n_active, n_changed, max_ncut, n_need_tab]
+    // The LP launch before this round may have dumped the tableau it ended with (have_dump): K2 reads
+    // that, except where rows were just removed -- need_tab marks the nodes whose tableau has to be
+    // worked out by a launch of its own (all generating nodes without have_dump).
+    int have_dump = 0;
+    int32_t *need_tab = nullptr;   // batch: out
 };
 // One wave per node.  round > 0: the stall test of the round just finished (base_node.py:320-324).
 // Then base_node.py:196-203's loop condition, and for the nodes that go on: clip (left to K2 / K3),
@@ -276,6 +281,9 @@ __global__ __launch_bounds__(64) void cut_round_begin(CutRoundArgs g) {
         g.state[CF_STALLED * B + k] = stalled;
         g.active[k] = act ? 1 : 0;
         g.resolve[k] = (act && nrem > 0) ? 1 : 0;
+        const int tab = (act && (nrem > 0 || !g.have_dump)) ? 1 : 0;
+        if (g.need_tab) g.need_tab[k] = tab;
+        if (tab) atomicAdd(&g.counters[3], 1);
         if (act) {
             g.state[CF_ROUNDS * B + k] = rounds + 1;
             g.obj_before[k] = obj;
