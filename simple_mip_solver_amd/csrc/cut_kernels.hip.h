@@ -506,18 +506,62 @@ struct SelectArgs {
 };
 
 // fold-in-half sum of f(j) over j < n2 (power of two, >= 64) by one wave; result in every lane
-template <typename F>
-__device__ inline double wave_fold(int n2, int lane, F f) {
-    double e[16];
-    const int per = n2 / 64;  // <= 16 (n <= 1024)
+// (PER = n2 / 64 is a compile-time constant: with a run-time trip count the 16-entry array lived in
+// scratch memory and every fold was a round trip through it)
+template <int PER>
+__device__ __forceinline__ double wave_fold_regs(double (&e)[PER]) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) e[k] = k < per ? f(lane + 64 * k) : 0.0;
-    for (int h = per / 2; h >= 1; h >>= 1)
+    for (int h = PER / 2; h >= 1; h >>= 1) {
+#pragma unroll
         for (int k = 0; k < h; k++) e[k] = e[k] + e[k + h];
+    }
     double s = e[0];
     for (int h = 32; h >= 1; h >>= 1) s = s + __shfl_down(s, h, 64);
     return __shfl(s, 0, 64);
 }
+
+// per-cut statistics of one pool cut by one wave: support, largest |coefficient|, pi . x, pi . pi
+template <int PER>
+__device__ __forceinline__ void cut_stats(const double *pk, const double *x, int clip_x, int n, int lane,
+                                          int &sup, double &mx, double &dot, double &sq) {
+    double v[PER], t[PER], q[PER];
+    sup = 0;
+    mx = 0.0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int j = lane + 64 * k;
+        v[k] = j < n ? pk[j] : 0.0;
+        const double xv = j < n ? (clip_x ? fmax(x[j], 0.0) : x[j]) : 0.0;
+        sup += (v[k] > kGoodEps) + (v[k] < -kGoodEps);
+        mx = fmax(mx, fabs(v[k]));
+        t[k] = j < n ? v[k] * xv : 0.0;
+        q[k] = j < n ? v[k] * v[k] : 0.0;
+    }
+    for (int h = 32; h >= 1; h >>= 1) sup += __shfl_down(sup, h, 64);
+    sup = __shfl(sup, 0, 64);
+    mx = wave_max_f64(mx);
+    dot = wave_fold_regs<PER>(t);
+    sq = wave_fold_regs<PER>(q);
+}
+
+template <int PER>
+__device__ __forceinline__ double cut_dot(const double *pk, const double *pa, int n, int lane) {
+    double t[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int j = lane + 64 * k;
+        t[k] = j < n ? pk[j] * pa[j] : 0.0;
+    }
+    return wave_fold_regs<PER>(t);
+}
+#define MIPX_PER_DISPATCH(per_, call_)     \
+    switch (per_) {                        \
+    case 1: { constexpr int PER = 1; call_; break; }   \
+    case 2: { constexpr int PER = 2; call_; break; }   \
+    case 4: { constexpr int PER = 4; call_; break; }   \
+    case 8: { constexpr int PER = 8; call_; break; }   \
+    default: { constexpr int PER = 16; call_; break; } \
+    }
 
 __global__ __launch_bounds__(256) void select_cuts(SelectArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -542,18 +586,9 @@ __global__ __launch_bounds__(256) void select_cuts(SelectArgs g) {
     // per-cut statistics, one wave per cut
     for (int k = wave; k < K; k += 4) {
         const double *pk = P + (size_t)row_of(k) * n;
-        int sup = 0;
-        double mx = 0.0;
-        for (int j = lane; j < n; j += 64) {
-            const double v = pk[j];
-            sup += (v > kGoodEps) + (v < -kGoodEps);
-            mx = fmax(mx, fabs(v));
-        }
-        for (int h = 32; h >= 1; h >>= 1) sup += __shfl_down(sup, h, 64);
-        sup = __shfl(sup, 0, 64);
-        mx = wave_max_f64(mx);
-        const double dot = wave_fold(n2, lane, [&](int j) { return j < n ? pk[j] * (g.clip_x ? fmax(x[j], 0.0) : x[j]) : 0.0; });
-        const double sq = wave_fold(n2, lane, [&](int j) { return j < n ? pk[j] * pk[j] : 0.0; });
+        int sup;
+        double mx, dot, sq;
+        MIPX_PER_DISPATCH(n2 >> 6, (cut_stats<PER>(pk, x, g.clip_x, n, lane, sup, mx, dot, sq)));
         if (lane == 0) {
             const double nr = sqrt(sq);
             nrm[k] = nr;
@@ -592,7 +627,8 @@ __global__ __launch_bounds__(256) void select_cuts(SelectArgs g) {
         __syncthreads();
         for (int a = wave; a < nadd; a += 4) {
             const double *pa = P + (size_t)row_of(add[a]) * n;
-            const double dot = wave_fold(n2, lane, [&](int j) { return j < n ? pk[j] * pa[j] : 0.0; });
+            double dot;
+            MIPX_PER_DISPATCH(n2 >> 6, (dot = cut_dot<PER>(pk, pa, n, lane)));
             if (lane == 0) {
                 double cs = dot / (nrm[k] * nrm[add[a]]);
                 cs = fmin(1.0, fmax(-1.0, cs));
@@ -612,5 +648,6 @@ __global__ __launch_bounds__(256) void select_cuts(SelectArgs g) {
     }
     if (tid == 0) { g.nadded[node] = nadd; g.terminator[node] = term; }
 }
+#undef MIPX_PER_DISPATCH
 
 }  // namespace mipx
