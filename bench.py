@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument('--tto-seconds', type=float, default=5.0, help='time limit of the time-to-optimal leg (0: skip)')
     ap.add_argument('--others', type=int, default=1, choices=[0, 1], help='1: also measure C2, C4, C5 (config.others)')
     ap.add_argument('--exchange-every', type=int, default=5, help='steps between exchanges (N > 1)')
-    ap.add_argument('--dive', type=int, default=4, choices=range(0, 9),
+    ap.add_argument('--dive', type=int, default=8, choices=range(0, 9),
                     help='dive children solved in a row on the tableau a node\'s workgroup holds (mipx_tree_set_dive; 0: off)')
     ap.add_argument('--reanchor', type=int, default=1, choices=[0, 1],
                     help='1: after sharding every open node gets an anchor of its own (mipx_tree_reanchor)')
