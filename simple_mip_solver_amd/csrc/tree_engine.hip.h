@@ -705,10 +705,14 @@ int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
         }
     }
     // per node: rounds and the six GMIC counters, its final number of cut rows
-    HIP_TRY(ctx, hipMemcpyAsync(S.h_cs + 4, S.cs_state, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    for (int f = 1; f < 7; f++)
-        HIP_TRY(ctx, hipMemcpyAsync(S.h_cs + 4 + (size_t)f * MB, S.cs_state + (size_t)f * B, (size_t)B * 4,
-                                    hipMemcpyDeviceToHost, st));
+    // (fields 0..6 lie behind one another on the device; with a full batch also on the host: one copy)
+    if ((size_t)B == MB) {
+        HIP_TRY(ctx, hipMemcpyAsync(S.h_cs + 4, S.cs_state, 7 * (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    } else {
+        for (int f = 0; f < 7; f++)
+            HIP_TRY(ctx, hipMemcpyAsync(S.h_cs + 4 + (size_t)f * MB, S.cs_state + (size_t)f * B, (size_t)B * 4,
+                                        hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(ctx, hipMemcpyAsync(S.h_cs + 4 + 7 * MB, S.w_ncut, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(S.h_cs + 4 + 8 * MB, S.cs_state + (size_t)mipx::CF_DROPPED * B, (size_t)B * 4,
                                 hipMemcpyDeviceToHost, st));
