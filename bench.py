@@ -403,9 +403,12 @@ def main():
         comm = _ffi.Comm(ctx, 0, 1, unique_id=_ffi.comm_unique_id())
     A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=args.seed)
     prob = _ffi.Problem(ctx, A, b, c)
+    # room for every child the timed steps can queue (a step's claim: two children per output level of each
+    # node), but never more than 160 GB of HBM for the node pool (a record: l, u, the basis)
+    pool_nodes = (2 + 2 * args.dive) * B * (args.steps + args.warmup + 8) + 4 * B * world
+    pool_nodes = min(pool_nodes, int(160e9 // (2 * 8 * n + n + m)))
     tree = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', search_rule='best first',
-                     strong_branch_iters=5, max_batch=B,
-                     pool_capacity=(2 + 2 * args.dive) * B * (args.steps + args.warmup + 8) + 4 * B * world)
+                     strong_branch_iters=5, max_batch=B, pool_capacity=pool_nodes)
     if not args.no_anchor:
         tree.set_anchor_mode(True)  # warm starts refactor from the root's optimal tableau
     if args.dive:
