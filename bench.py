@@ -459,7 +459,8 @@ def main():
         tree.set_comm(None)
 
     if rank == 0:
-        assert np.all(allr[:, 8] >= args.steps), f'a rank ran fewer than {args.steps} steps: {allr[:, 8]}'
+        assert np.all(allr[:, 8] >= args.steps), (f'a rank ran fewer than {args.steps} steps: {allr[:, 8]} '
+                                                 '(the node pool is capped at 160 GB: fewer --steps, or a smaller --dive / --batch)')
         elapsed_max = float(allr[:, 0].max())
         lps_total, probes_total = float(allr[:, 1].sum()), float(allr[:, 2].sum())
         gp = float(allr[:, 6].min()); gd = float(allr[:, 7].min())

@@ -259,6 +259,34 @@ def test_frontier_batches_with_cuts_find_feasible_incumbents(Node):
                 assert bb._native_cuts_dropped == 0
 
 
+@pytest.mark.parametrize('n,m,seed', [(20, 10, 1), (40, 16, 3), (64, 32, 0), (256, 128, 0)])
+def test_the_tableau_a_solve_ends_with_serves_the_cut_rounds(n, m, seed):
+    """Without exact_tableau K2 reads the tableau the LP launch itself ends with (dumped by that launch)
+    instead of one refactored from the slack basis by a launch of its own: two tableaus of the same basis
+    that differ in their last bits.  At the root the cut rounds must come out the same: rounds, GMICs
+    created / added / removed, and the bound after the last round."""
+    from simple_mip_solver_amd.generators import random_dense_milp_arrays
+    A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=seed)
+    ctx = _ffi.default_context()
+    prob = _ffi.Problem(ctx, A, b, c)
+    out = []
+    for exact in (1, 0):
+        t = _ffi.Tree(prob, ints, l, u, branch_rule='most fractional', max_batch=4, pool_capacity=64,
+                      cut_params=dict(max_abs_coef=1000.0 * float(np.max(np.abs(A))), exact_tableau=exact))
+        if not exact:
+            t.set_anchor_mode(True)
+        st = t.solve(mip_gap=0.0, frontier_batch=4, node_limit=1)
+        out.append((st, t.cut_stats()))
+        t.close()
+    (se, ce), (sf, cf) = out
+    assert se['evaluated_nodes'] == sf['evaluated_nodes'] == 1
+    assert ce['total_cut_generation_iterations'] >= 1 and ce['total_number_gmic_created'] > 0
+    for key in _ffi.CUT_TOTAL_KEYS:
+        assert ce[key] == cf[key], (key, ce, cf)
+    assert isclose(se['dual_bound'], sf['dual_bound'], rel_tol=1e-9, abs_tol=1e-9)
+    prob.close()
+
+
 def test_example_models_batched_with_cuts():
     for f, rec in sorted(TABLE.items()):
         path = os.path.join(HERE, 'golden', 'example_models', f)
