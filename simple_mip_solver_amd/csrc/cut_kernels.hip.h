@@ -299,24 +299,41 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
     __syncthreads();
     // ---- which cuts there are (uniform over the workgroup), and which are this workgroup's ---------
     // rows whose basic variable is an integer structural with a fractional value (f0 in [0.01, 0.99])
+    // (one rank per thread, compacted in rank order: a ballot per wave, the waves' counts through LDS)
     int ncuts = 0;
-    for (int rank = 0; rank < m; rank++) {
-        const int r = order[rank];
-        const int v = bvar_s[r];
-        bool gen = v < n && g.is_int[v < n ? v : 0];
+    for (int base = 0; base < m; base += NT) {
+        const int rank = base + tid;
+        bool gen = false;
         double f0 = 0.0;
-        if (gen) {
-            const double xv = g.clip_x ? fmax(x[v], 0.0) : x[v];
-            const double fl = floor(xv), ce = ceil(xv);
-            gen = fmin(xv - fl, ce - xv) > kVarEpsCut;
-            f0 = xv - fl;
-            if (f0 < kGoodEps || f0 + kGoodEps > 1.0) gen = false;
+        if (rank < m) {
+            const int r = order[rank];
+            const int v = bvar_s[r];
+            gen = v < n && g.is_int[v < n ? v : 0];
+            if (gen) {
+                const double xv = g.clip_x ? fmax(x[v], 0.0) : x[v];
+                const double fl = floor(xv), ce = ceil(xv);
+                gen = fmin(xv - fl, ce - xv) > kVarEpsCut;
+                f0 = xv - fl;
+                if (f0 < kGoodEps || f0 + kGoodEps > 1.0) gen = false;
+            }
         }
-        if (!gen) continue;
-        if (tid == 0) { cut_rank[ncuts] = rank; cut_f0[ncuts] = f0; }
-        ncuts++;
+        const unsigned long long bal = __ballot(gen);
+        if (lane == 0) red[wave] = (double)__popcll(bal);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < NT / 64; w++) {
+            const int c = (int)red[w];
+            before += w < wave ? c : 0;
+            total += c;
+        }
+        if (gen) {
+            const int pos = ncuts + before + __popcll(bal & ((1ull << lane) - 1ull));
+            cut_rank[pos] = rank;
+            cut_f0[pos] = f0;
+        }
+        ncuts += total;
+        __syncthreads();
     }
-    __syncthreads();
     // ---- this workgroup's cuts, GRP at a time: the slack substitution of a group reads every row of
     // A once for all of them (one cut at a time re-read the 256 KiB of A from L2 per cut: the kernel
     // was bound by that).  Per cut the arithmetic and its order are unchanged.
