@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void get_fraction_batch(FractionArgs g) {
 constexpr int kGomoryGroup = 8;
 // dynamic LDS of gomory_cuts for n columns, ms allotted rows and `group` cuts at a time
 inline size_t gomory_lds_bytes(int n, int ms, int group) {
-    return ((size_t)group * (n + ms) + ms + 64) * 8 + (3 * (size_t)ms + n) * 4 + 64;
+    return ((size_t)group * (n + ms) + ms + 128) * 8 + (3 * (size_t)ms + n) * 4 + 64;
 }
 // the largest group whose staging fits 48 KiB of LDS
 inline int gomory_group(int n, int ms) {
@@ -259,12 +259,12 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
     const int ms = g.mstride ? g.mstride : m0;     // rows allotted per node in the strided arrays
     const int32_t *cids = g.ncut ? g.cut_ids + (size_t)node * g.cut_stride : nullptr;
     const double INF = __builtin_huge_val();
-    // dynamic LDS carve (sized for ms rows): group x (pi_var[n] | ps[ms]) | cut_f0[ms] | red[64] |
+    // dynamic LDS carve (sized for ms rows): group x (pi_var[n] | ps[ms]) | cut_f0[ms] | red[128] |
     // order[ms] | bvar[ms] | nvar[n] | cut_rank[ms]      (gomory_lds_bytes)
     double *pi_var = (double *)smem_raw;
     double *cut_f0 = pi_var + (size_t)g.group * (n + ms);
     double *red = cut_f0 + ms;
-    int *order = (int *)(red + 64);   // order[rank] = tableau row
+    int *order = (int *)(red + 128);  // order[rank] = tableau row
     int *bvar_s = order + ms;
     int *nvar_s = bvar_s + ms;
     int *cut_rank = nvar_s + n;
@@ -405,42 +405,46 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
             }
         }
         __syncthreads();
-        for (int q = 0; q < gc; q++) {
+        // ---- the group's right-hand sides, scales and rounding: per cut the arithmetic of the reference,
+        // but the cuts of a group go through each stage together (three barriers per group, not per cut)
+        constexpr int NW = NT / 64;
+        double *rhs_s = red;               // [kGomoryGroup]
+        double *smin_s = red + kGomoryGroup;                 // [kGomoryGroup][NW]
+        double *any_s = red + kGomoryGroup * (1 + NW);        // [kGomoryGroup][NW]
+        // rhs = 1 + ps . b with a fold-in-half tree over the next power of two: wave w takes cuts w, w + NW, ..
+        for (int q = wave; q < gc; q += NW) {
             const int cq = c0 + q * g.chunks;
-            const int rank = cut_rank[cq];
-            double *pv = pi_var + (size_t)q * (n + ms), *psq = pv + n;
-            // rhs = 1 + ps . b with a fold-in-half tree over the next power of two (wave 0)
-            if (wave == 0) {
-                int m2 = 1;
-                while (m2 < m) m2 <<= 1;
-                double part = 0.0;
-                auto rhs_of = [&](int j) { return j < m0 ? g.b[j] : g.cut_pi0[cids[j - m0]]; };
-                if (m2 <= 64) {
-                    part = lane < m ? psq[lane] * rhs_of(lane) : 0.0;
-                    for (int h = m2 / 2; h >= 1; h >>= 1) part = part + __shfl_down(part, h, 64);
-                } else {
-                    // lane holds elements lane + 64*k: fold the k levels in registers, then across lanes
-                    double e[16];
-                    const int per = m2 / 64;  // <= 16 for m <= 1024
-                    for (int k = 0; k < 16; k++) {
-                        const int j = lane + 64 * k;
-                        e[k] = (k < per && j < m) ? psq[j] * rhs_of(j) : 0.0;
-                    }
-                    for (int h = per / 2; h >= 1; h >>= 1)
-                        for (int k = 0; k < h; k++) e[k] = e[k] + e[k + h];
-                    part = e[0];
-                    for (int h = 32; h >= 1; h >>= 1) part = part + __shfl_down(part, h, 64);
+            const double *psq = pi_var + (size_t)q * (n + ms) + n;
+            int m2 = 1;
+            while (m2 < m) m2 <<= 1;
+            double part = 0.0;
+            auto rhs_of = [&](int j) { return j < m0 ? g.b[j] : g.cut_pi0[cids[j - m0]]; };
+            if (m2 <= 64) {
+                part = lane < m ? psq[lane] * rhs_of(lane) : 0.0;
+                for (int h = m2 / 2; h >= 1; h >>= 1) part = part + __shfl_down(part, h, 64);
+            } else {
+                // lane holds elements lane + 64*k: fold the k levels in registers, then across lanes
+                double e[16];
+                const int per = m2 / 64;  // <= 16 for m <= 1024
+                for (int k = 0; k < 16; k++) {
+                    const int j = lane + 64 * k;
+                    e[k] = (k < per && j < m) ? psq[j] * rhs_of(j) : 0.0;
                 }
-                if (lane == 0) {
-                    const double rhs = 1.0 + part;
-                    if (g.pi0) g.pi0[(size_t)node * ms + cq] = rhs;
-                    if (g.row_idx) g.row_idx[(size_t)node * ms + cq] = rank;
-                    red[0] = rhs;
-                }
+                for (int h = per / 2; h >= 1; h >>= 1)
+                    for (int k = 0; k < h; k++) e[k] = e[k] + e[k + h];
+                part = e[0];
+                for (int h = 32; h >= 1; h >>= 1) part = part + __shfl_down(part, h, 64);
             }
-            __syncthreads();
-            // ---- numerically safe rounding (estimate 'over'; rhs 'under') -----------------------
-            // scale = min_j |1 / coef_j|
+            if (lane == 0) {
+                const double rhs = 1.0 + part;
+                if (g.pi0) g.pi0[(size_t)node * ms + cq] = rhs;
+                if (g.row_idx) g.row_idx[(size_t)node * ms + cq] = cut_rank[cq];
+                rhs_s[q] = rhs;
+            }
+        }
+        // scale = min_j |1 / coef_j| (min is order independent): the waves' minima through LDS
+        for (int q = 0; q < gc; q++) {
+            const double *pv = pi_var + (size_t)q * (n + ms);
             double smin = INF;
             bool any = false;
             for (int var = tid; var < n; var += NT) {
@@ -448,14 +452,18 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
                 any |= c != 0.0;
                 smin = fmin(smin, fabs(1.0 / c));
             }
-            // block reduction (min is order independent)
             smin = -wave_max_f64(-smin);
             const int anyw = __any(any);
-            if (lane == 0) { red[1 + wave] = smin; red[33 + wave] = anyw; }
-            __syncthreads();
+            if (lane == 0) { smin_s[q * NW + wave] = smin; any_s[q * NW + wave] = anyw; }
+        }
+        __syncthreads();
+        // numerically safe rounding (estimate 'over'; rhs 'under'), cut after cut without a barrier
+        for (int q = 0; q < gc; q++) {
+            const int cq = c0 + q * g.chunks;
+            const double *pv = pi_var + (size_t)q * (n + ms);
             double scale = INF;
             bool nonzero = false;
-            for (int wv = 0; wv < NT / 64; wv++) { scale = fmin(scale, red[1 + wv]); nonzero |= red[33 + wv] != 0.0; }
+            for (int wv = 0; wv < NW; wv++) { scale = fmin(scale, smin_s[q * NW + wv]); nonzero |= any_s[q * NW + wv] != 0.0; }
             // where the rounded cut goes: row cq of the node's block of safe_pi, or (engine) the next
             // free rows of the node's pool slab; a full slab drops the cut
             double *out_sp = nullptr, *out_s0 = nullptr;
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
             if (out_sp != nullptr) {   // (uniform)
                 if (!nonzero) {
                     for (int var = tid; var < n; var += NT) out_sp[var] = pv[var];
-                    if (tid == 0) *out_s0 = red[0];
+                    if (tid == q) *out_s0 = rhs_s[q];
                 } else {
                     for (int var = tid; var < n; var += NT) {
                         const double coef = pv[var] * scale;
@@ -480,15 +488,15 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
                         safe_coef_dev(coef, g.max_term, kEstOver, nn, dd);
                         out_sp[var] = nn / dd;
                     }
-                    if (tid == 0) {
+                    if (tid == q) {   // (the right-hand sides of the group's cuts on different threads)
                         double n0, d0;
-                        get_fraction_dev(red[0] * scale, 1e3, kEstUnder, n0, d0);
+                        get_fraction_dev(rhs_s[q] * scale, 1e3, kEstUnder, n0, d0);
                         *out_s0 = n0 / d0;
                     }
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
     // (engine: the new slab rows join the node's pool in pool_append, after every workgroup of the
     // node is done with slab_n)
