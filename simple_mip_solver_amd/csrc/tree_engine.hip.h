@@ -360,7 +360,15 @@ void tree_queue_ids(const mipx_tree *t, std::vector<int64_t> &out) {
     }
 }
 
+#ifdef MIPX_HOSTPROF
+#include <x86intrin.h>
+static unsigned long long g_hp_push = 0, g_hp_rec = 0, g_hp_n = 0;
+#endif
 void tree_push(mipx_tree *t, int64_t id) {
+#ifdef MIPX_HOSTPROF
+    const unsigned long long t0_ = __rdtsc();
+    struct Acc { unsigned long long t0; ~Acc() { g_hp_push += __rdtsc() - t0; g_hp_n++; } } acc_{t0_};
+#endif
     if (t->use_bq) t->bq.push(t->nodes[id].key, id);
     else t->heap.push(t->nodes[id].key, id);
     if (t->search != 0) {  // depth first: the dual bound comes from a lazy heap over the open nodes
@@ -965,7 +973,13 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
                     c.slot = t->free_slots.back();
                     t->free_slots.pop_back();
                     S.br[(size_t)level].child.push_back(c.slot);
+#ifdef MIPX_HOSTPROF
+                    const unsigned long long r0_ = __rdtsc();
+#endif
                     t->nodes.push_back(c);
+#ifdef MIPX_HOSTPROF
+                    g_hp_rec += __rdtsc() - r0_;
+#endif
                     const int64_t cid = (int64_t)t->nodes.size() - 1;
                     if (take_dive && dir == ddir[pos]) {
                         dive_child = cid;  // already solved: never enters the queue
@@ -1689,6 +1703,11 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
                      t->phase_ms[0] - ph0[0], t->phase_ms[1] - ph0[1], t->phase_ms[2] - ph0[2] + t->phase_ms[5] - ph0[5] + t->phase_ms[6] - ph0[6],
                      t->phase_ms[3] - ph0[3], t->phase_ms[4] - ph0[4], t->kernel_ms - k0,
                      t->phase_ms[5] - ph0[5], t->phase_ms[6] - ph0[6], t->phase_ms[2] - ph0[2]);
+#ifdef MIPX_HOSTPROF
+        std::fprintf(stderr, "[mipx_tree]   hostprof: %llu queue pushes %.1f ms (%.0f cycles each), node records %.1f ms\n",
+                     g_hp_n, g_hp_push / 2.0e6, g_hp_n ? (double)g_hp_push / g_hp_n : 0.0, g_hp_rec / 2.0e6);
+        g_hp_push = g_hp_rec = g_hp_n = 0;
+#endif
         std::fprintf(stderr, "[mipx_tree]   popped so far by age in steps: 1:%lld 2:%lld 3:%lld 4:%lld 5:%lld 6:%lld 7+:%lld  mean depth %.1f\n",
                      (long long)t->age_hist[1], (long long)t->age_hist[2], (long long)t->age_hist[3], (long long)t->age_hist[4],
                      (long long)t->age_hist[5], (long long)t->age_hist[6], (long long)t->age_hist[7],
