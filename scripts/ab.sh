@@ -9,6 +9,6 @@ for i in $(seq 1 $N); do
     MIPX_LIB=$R/simple_mip_solver_amd/csrc/$L timeout -k 10 150 python3 $R/bench.py $ARGS 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$L', 'launch_ms %.4f' % d['roofline']['launch_ms'], 'value %.0f' % d['value'], flush=True)"
+print('$L', 'launch_ms %.4f' % d['roofline']['launch_ms'], 'ms_per_step %.4f' % d['ms_per_step'], 'value %.0f' % d['value'], flush=True)"
   done
 done
