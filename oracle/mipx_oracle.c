@@ -98,13 +98,15 @@ void mipx_oracle_set_dump(double *T, double *vec, int32_t *idx) {
 static const double *g_anchor_T = 0, *g_anchor_vec = 0;
 static const int32_t *g_anchor_idx = 0;
 static int g_refactor_only = 0;
-/* pricing rule of the node LPs: -1 = what the GPU path runs for the shape (1 where the register-tile
- * kernel takes it: m <= 192 and n <= 256 with the tile table of csrc/mipx.hip, else 0) */
+/* pricing rule of the node LPs: 0 largest violation, 1 dual steepest edge, 2 dual Devex; -1 = what the GPU
+ * path runs for the shape (1 where the register-tile kernel takes it: m <= 192 and n <= 256 with the tile
+ * table of csrc/mipx.hip; else 2: the HBM-streaming kernel cannot afford the extra tableau pass the
+ * steepest-edge inner products would take, Devex weights need the pivot column only) */
 static int g_pricing = -1;
 void mipx_oracle_set_pricing(int pricing) { g_pricing = pricing; }
 static int pricing_for(int m, int n) {
     if (g_pricing >= 0) return g_pricing;
-    return ((m <= 32 && n <= 64) || (m <= 64 && n <= 128) || (m <= 128 && n <= 256) || (m <= 192 && n <= 256)) ? 1 : 0;
+    return ((m <= 32 && n <= 64) || (m <= 64 && n <= 128) || (m <= 128 && n <= 256) || (m <= 192 && n <= 256)) ? 1 : 2;
 }
 #define MIPX_DSE_REFRESH 64
 void mipx_oracle_set_anchor(const double *T, const double *vec, const int32_t *idx) {
@@ -307,9 +309,12 @@ static int lp_solve_impl(int m, int n, const double *A, const double *b, const d
 
     /* 3'. dual steepest edge weights (pricing 1): squared norms of the rows of [I | T] */
     const int dse = pricing_for(m, n) == 1;
+    const int devex = pricing_for(m, n) == 2;
     double *wgt = (double *)malloc(sizeof(double) * (size_t)(m + 1));
     double *tau = (double *)malloc(sizeof(double) * (size_t)(m + 1));
     int wage = 0; /* iterations since the weights were exact */
+    /* 3''. Devex (pricing 2): reference weights 1 at the start of a node LP (a dive goes on with them) */
+    if (devex) for (int i = 0; i < m; i++) wgt[i] = 1.0;
     if (dse && !g_refactor_only) {
         for (int i = 0; i < m; i++) {
             const double *Ti = t.T + (size_t)i * n;
@@ -345,7 +350,7 @@ next_pass:
                 else if (!isinf(up) && a > up + MIPX_PTOL) { level = 1; viol = a - up; sg = -1; }
             }
             if (level == 0) continue;
-            if (dse) viol = viol * viol / wgt[i];
+            if (dse || devex) viol = viol * viol / wgt[i];
             if (bland) { level = 1; viol = 0.0; } /* Bland: lowest variable index among violated */
             int better = 0;
             if (r < 0) better = 1;
@@ -406,6 +411,17 @@ next_pass:
             else { la = 0.0; lb = 1.0; newside = 2; }
             const double p = Tr[q];
             const double pinv = 1.0 / p;
+            if (devex) { /* w_i <- max(w_i, (alpha_i / p)^2 w_r), w_r <- max(w_r / p^2, 1) */
+                const double wr = wgt[r];
+                for (int i = 0; i < m; i++) {
+                    if (i == r) continue;
+                    const double ratio = t.T[(size_t)i * n + q] * pinv;
+                    const double w = (ratio * ratio) * wr;
+                    wgt[i] = w > wgt[i] ? w : wgt[i];
+                }
+                const double w = (wr * pinv) * pinv;
+                wgt[r] = w < 1.0 ? 1.0 : w;
+            }
             if (dse) { /* the weights after the row operations of this pivot */
                 for (int i = 0; i < m; i++) {
                     const double *Ti = t.T + (size_t)i * n;

@@ -111,9 +111,9 @@ def lp_solve_dive_batch(A, b, c, l, u, vstat, rule, int_idx, cost_l, cost_r, has
 
 
 class pricing:
-    """Context manager: force the pricing rule of the oracle's node LPs (0 largest violation -- what
-    the HBM-streaming kernel runs --, 1 dual steepest edge -- the register-tile kernel); the default
-    (-1) follows the GPU path's choice by shape."""
+    """Context manager: force the pricing rule of the oracle's node LPs (0 largest violation, 1 dual
+    steepest edge -- the register-tile kernel --, 2 dual Devex -- the HBM-streaming kernel); the
+    default (-1) follows the GPU path's choice by shape."""
 
     def __init__(self, rule):
         self.rule = int(rule)

@@ -4,8 +4,9 @@
 // HBM scratch slab and is STREAMED once per pivot (one coalesced read + one write of every row):
 // this is the regime SURVEY.md section 8(d) prices, 2*8*(m+1)(n+m+1) bytes per pivot, and the
 // kernel is bound by HBM bandwidth.  Borders and the pivot row/column live in LDS (dynamic,
-// ~100 KiB at 1024 x 512).  Same arithmetic, same selections, same reductions as K1, so results
-// are bit-identical to the oracle.
+// ~100 KiB at 1024 x 512).  Same arithmetic and reductions as K1; the leaving row is priced with dual
+// Devex weights (w_i from the pivot column alone: the inner products of K1's steepest edge would take
+// another pass over the tableau).  Results are bit-identical to the oracle's for these shapes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,7 +20,7 @@ constexpr int kBigMaxN = 1024;  // 16 elements per lane in the wave folds
 constexpr int kBigMaxM = 1024;
 
 __host__ __device__ inline size_t big_lds_bytes(int m, int n) {
-    const size_t dbl = (size_t)n * 10 + (size_t)m * 4 + 8;   // row d va vb lo up key aabs dje x | alpha beta0 ba bb | cd
+    const size_t dbl = (size_t)n * 10 + (size_t)m * 5 + 8;   // row d va vb lo up key aabs dje x | alpha beta0 ba bb wgt | cd
     const size_t i32 = (size_t)n * 3 + (size_t)m + 8 + (size_t)(n + m);  // nvar side wlist | bvar | nw ci | pos
     const size_t i8 = 2 * (size_t)(n + m) + (size_t)m;       // wantb atup | entered
     return dbl * 8 + i32 * 4 + i8 + 64;
@@ -42,7 +43,8 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
     double *s_d = s_row + n, *s_va = s_d + n, *s_vb = s_va + n, *s_lo = s_vb + n, *s_up = s_lo + n;
     double *s_key = s_up + n, *s_aabs = s_key + n, *s_dje = s_aabs + n, *s_x = s_dje + n;
     double *s_alpha = s_x + n, *s_beta0 = s_alpha + m, *s_ba = s_beta0 + m, *s_bb = s_ba + m;
-    double *s_cd = s_bb + m;
+    double *s_wgt = s_bb + m;           // dual Devex weights of the rows (reference framework: 1 at the start of a node LP)
+    double *s_cd = s_wgt + m;
     int *s_nvar = (int *)(s_cd + 8), *s_side = s_nvar + n, *s_wlist = s_side + n, *s_bvar = s_wlist + n;
     int *s_ci = s_bvar + m;             // [0..3] control words, [4] nw
     int *s_pos = s_ci + 8;              // column of each variable in the starting tableau, -1 if basic
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                     }
                     if (lane == 0) { s_ba[i] = s_beta0[i] - sa; s_bb[i] = 0.0 - sb; }
                 }
+                for (int i = tid; i < m; i += NT) s_wgt[i] = 1.0;   // Devex: a fresh reference framework
                 __syncthreads();
                 phase = 2;
                 continue;
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                                 if (a < lo - kPTol) { level = 1; viol = lo - a; sg = 1; }
                                 else if (!isinf(up) && a > up + kPTol) { level = 1; viol = a - up; sg = -1; }
                             }
+                            if (level > 0) viol = viol * viol / s_wgt[i];   // dual Devex pricing
                             if (bland && level > 0) { level = 1; viol = 0.0; }
                             const int pay = (v << 16) | (sg < 0 ? 0x8000 : 0) | i;
                             const bool up_lvl = level > blevel;
@@ -316,6 +320,7 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
             }
             const double dq = s_d[q], b0r = s_beta0[r];
             const double bar = s_ba[r], bbr = s_bb[r], vaq = s_va[q], vbq = s_vb[q];
+            const double wr = s_wgt[r];
             __syncthreads();
             {   // ---- stream the tableau: T_ij <- fma(-alpha_i, rho_j, T_ij) ---------------------
                 const bool vals = phase == 2;
@@ -390,12 +395,22 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                 const double ta = (bar - la) * pinv, tb = (bbr - lb) * pinv;
                 for (int i = tid; i < m; i += NT) {
                     const double a = s_alpha[i];
+                    // (Devex weights with the values: w_i <- max(w_i, (alpha_i / p)^2 w_r), w_r <- max(w_r / p^2, 1))
                     if (i == r) {
                         s_beta0[i] = rhon;
-                        if (vals) { s_ba[i] = vaq + ta; s_bb[i] = vbq + tb; }
+                        if (vals) {
+                            s_ba[i] = vaq + ta; s_bb[i] = vbq + tb;
+                            const double w = (wr * pinv) * pinv;
+                            s_wgt[i] = w < 1.0 ? 1.0 : w;
+                        }
                     } else {
                         s_beta0[i] = fma(-a, rhon, s_beta0[i]);
-                        if (vals) { s_ba[i] = fma(-a, ta, s_ba[i]); s_bb[i] = fma(-a, tb, s_bb[i]); }
+                        if (vals) {
+                            s_ba[i] = fma(-a, ta, s_ba[i]); s_bb[i] = fma(-a, tb, s_bb[i]);
+                            const double ratio = a * pinv;
+                            const double w = (ratio * ratio) * wr;
+                            s_wgt[i] = w > s_wgt[i] ? w : s_wgt[i];
+                        }
                     }
                 }
                 for (int j = tid; j < n; j += NT) {
