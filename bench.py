@@ -339,9 +339,11 @@ def other_configs(args, ctx):
     n5, m5, B5, steps5 = 1024, 512, 1024, 5
     A5, b5, c5, l5, u5, ints5 = random_dense_milp_arrays(n5, m5, seed=0)
     p5 = _ffi.Problem(ctx, A5, b5, c5)
-    t5 = _ffi.Tree(p5, ints5, l5, u5, branch_rule='pseudo cost', max_batch=B5, pool_capacity=64 * B5)
+    depth5 = max(1, args.dive)
+    t5 = _ffi.Tree(p5, ints5, l5, u5, branch_rule='pseudo cost', max_batch=B5,
+                   pool_capacity=(2 + 2 * depth5) * B5 * (steps5 + 3) + 16 * B5)
     t5.set_anchor_mode(True)
-    t5.set_dive(True)
+    t5.set_dive(depth5)
     st = t5.stats()
     while st['open_nodes'] < B5 or st['evaluated_nodes'] == 0:
         st = t5.solve(mip_gap=0.0, frontier_batch=min(B5, 256), max_steps=1)
@@ -356,8 +358,8 @@ def other_configs(args, ctx):
     model = algorithmic_bytes(m5, n5, d5['lp_solved'], d5['pivots'], d5['dives'])
     real = d5['pivots'] * 2 * 8 * m5 * n5   # what K1b streams: the condensed m x n tableau, read + written per pivot
     out['C5_single_gpu'] = {
-        'workload': f'1024 vars x 512 rows, seed 0, as C3, {B5} nodes per step + dive children, anchored (one GPU of the '
-                    f'8 the config names)', 'kernel': _ffi.kernel_name(m5, n5),
+        'workload': f'1024 vars x 512 rows, seed 0, as C3, {B5} nodes per step + in-place dive of depth {depth5}, anchored '
+                    f'(one GPU of the 8 the config names)', 'kernel': _ffi.kernel_name(m5, n5),
         'lps_per_s': d5['lp_solved'] / el, 'kernel_lps_per_s': d5['lp_solved'] / ks, 'ms_per_step': el / max(1, d5['steps']) * 1e3,
         'mean_pivots_per_lp': d5['pivots'] / max(1, d5['lp_solved']),
         'roofline': {'bound': 'hbm', 'achieved': real / ks / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',

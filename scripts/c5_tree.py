@@ -6,7 +6,7 @@ from simple_mip_solver_amd import _ffi
 from simple_mip_solver_amd.generators import random_dense_milp_arrays
 n, m = 1024, 512
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-dive = (sys.argv[2] != '0') if len(sys.argv) > 2 else True
+dive = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # depth of the in-place dive (0: off)
 ctx = _ffi.default_context()
 A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=0)
 p = _ffi.Problem(ctx, A, b, c)

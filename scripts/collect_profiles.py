@@ -88,8 +88,8 @@ if fe and wr:
     for r in csv.DictReader(open(O + f'/{TAG}_k1b_kernel_by_grid.csv')):
         if 'lp_dual_simplex_big' in r['kernel'] and int(r['grid_x']) == g:
             dur = float(r['avg_us'])
-    k1b = {"command": "rocprofv3 (trace / --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes) -- python3 scripts/c5_tree.py 1024 1",
-           "kernel": f"lp_dual_simplex_big (K1b) at 1024 x 512, grid {g} threads (1024 nodes + dive children per launch)",
+    k1b = {"command": "rocprofv3 (trace / --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes) -- python3 scripts/c5_tree.py 1024 8",
+           "kernel": f"lp_dual_simplex_big (K1b) at 1024 x 512, grid {g} threads (1024 nodes + their plunge of depth 8 per launch)",
            "fetch_size_KB_raw": f_kb, "write_size_KB": w_kb, "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024,
            "avg_launch_us": dur,
            "hbm_GBps": None if not dur else (2 * f_kb + w_kb) * 1024 / (dur * 1e-6) / 1e9}
