@@ -312,6 +312,7 @@ def other_configs(args, ctx):
     st = t.stats()
     while st['open_nodes'] < B4 or st['evaluated_nodes'] == 0:
         st = t.solve(mip_gap=0.0, frontier_batch=min(B4, 1024), max_steps=1)
+    t.reanchor(st['open_nodes'])   # as C3: the open nodes (none carries a cut row here) get anchors of their own
     b0, c0 = t.stats(), t.cut_stats()
     ctx.sync()
     t0 = time.perf_counter()

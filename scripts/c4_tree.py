@@ -20,6 +20,8 @@ t.set_anchor_mode(True)
 st = t.stats()
 while st['open_nodes'] < B or st['evaluated_nodes'] == 0:
     st = t.solve(mip_gap=0.0, frontier_batch=min(B, 1024), max_steps=1)
+if not exact and (len(sys.argv) <= 6 or sys.argv[6] != '0'):
+    t.reanchor(st['open_nodes'])   # open nodes without cut rows get the tableau of their own basis as anchor
 before = t.stats(); c0 = t.cut_stats()
 t0 = time.perf_counter()
 st = t.solve(mip_gap=0.0, frontier_batch=B, max_steps=steps)

@@ -9,6 +9,7 @@
 // batches evaluate the B best open nodes per step against the table as of the start of the step.
 // Included by mipx.hip (needs mipx_ctx, mipx_problem, pick_cfg, HIP_TRY, fail).
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <limits>
@@ -584,7 +585,7 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
         }
         HIP_TRY(ctx, hipEventRecord(S.e0, st));
         rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, S.d_slot, 0, S.d_status, S.d_obj, S.d_x,
-                       S.d_vout, S.d_iters, S.d_npiv, nullptr, nullptr, nullptr, &cl);
+                       S.d_vout, S.d_iters, S.d_npiv, nullptr, nullptr, S.d_slot + B, &cl);
         if (rc) return rc;
         HIP_TRY(ctx, hipEventRecord(S.e1, st));
         if ((rc = launch_score(t, S, B, false, true))) return rc;
@@ -1734,7 +1735,6 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
 int mipx_tree_reanchor(mipx_tree *t, int64_t max_nodes) {
     if (!t || max_nodes < 1) return MIPX_EINVAL;
     mipx_ctx *ctx = t->ctx;
-    if (t->cuts) return fail(ctx, MIPX_EINVAL, "mipx_tree_reanchor: not available with cut rounds");
     if (!t->anchor_mode || !t->anchor_set)
         return fail(ctx, MIPX_EINVAL, "mipx_tree_reanchor: needs the anchor mode and a solved root");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1743,8 +1743,17 @@ int mipx_tree_reanchor(mipx_tree *t, int64_t max_nodes) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<int64_t> order;
     tree_queue_ids(t, order);
+    if (t->cuts) {   // an anchor is a tableau of the shared rows: only nodes that carry no cut row get one
+        std::stable_partition(order.begin(), order.end(), [&](int64_t id) { return t->nodes[id].ncut == 0; });
+        int64_t plain = 0;
+        for (int64_t id : order) plain += t->nodes[id].ncut == 0;
+        max_nodes = std::min<int64_t>(max_nodes, plain);
+    }
     const int64_t K = std::min<int64_t>(max_nodes, (int64_t)order.size());
-    if (K == 0) return MIPX_OK;
+    if (K == 0) {
+        for (int64_t id : order) t->nodes[id].anchor = -1;
+        return MIPX_OK;
+    }
     const size_t m = t->m, n = t->n;
     double *nT = nullptr, *nvec = nullptr;
     int32_t *nidx = nullptr, *d_sl = nullptr;
@@ -1765,6 +1774,18 @@ int mipx_tree_reanchor(mipx_tree *t, int64_t max_nodes) {
     a.A = t->prob->dA; a.b = t->prob->db; a.c = t->prob->dc;
     a.A_stride = a.b_stride = a.c_stride = 0;
     a.l = t->pool_l; a.u = t->pool_u; a.vstat_in = t->pool_v; a.slot = d_sl; a.max_iter = 0;
+    double *gl = nullptr, *gu = nullptr;
+    int8_t *gv = nullptr;
+    if (t->cuts) {   // (the pool's basis rows are n + mrows wide: dense copies over the shared rows)
+        HIP_TRY(ctx, hipMalloc((void **)&gl, (size_t)K * n * 8));
+        HIP_TRY(ctx, hipMalloc((void **)&gu, (size_t)K * n * 8));
+        HIP_TRY(ctx, hipMalloc((void **)&gv, (size_t)K * (n + m)));
+        mipx::PlainGatherArgs ga;
+        ga.n = (int)n; ga.m = (int)m; ga.nvs_pool = t->n + t->mrows; ga.count = (int)K; ga.slot = d_sl;
+        ga.pool_l = t->pool_l; ga.pool_u = t->pool_u; ga.pool_v = t->pool_v; ga.l = gl; ga.u = gu; ga.v = gv;
+        hipLaunchKernelGGL(mipx::gather_plain_nodes, dim3((unsigned)K), dim3(256), 0, st, ga);
+        a.l = gl; a.u = gu; a.vstat_in = gv; a.slot = nullptr;
+    }
     a.anchor_T = t->prob->anchor_on ? t->prob->anchor_T : nullptr;
     a.anchor_vec = t->prob->anchor_on ? t->prob->anchor_vec : nullptr;
     a.anchor_idx = t->prob->anchor_on ? t->prob->anchor_idx : nullptr;
@@ -1776,6 +1797,7 @@ int mipx_tree_reanchor(mipx_tree *t, int64_t max_nodes) {
     int rc = launch_lp_any(t->prob, a, (int)K, st);
     if (rc == MIPX_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, MIPX_EHIP, "mipx_tree_reanchor: launch failed");
     (void)hipFree(d_sl);
+    if (gl) { (void)hipFree(gl); (void)hipFree(gu); (void)hipFree(gv); }
     if (rc != MIPX_OK) { (void)hipFree(nT); (void)hipFree(nvec); (void)hipFree(nidx); return rc; }
     if (t->atab_T) { (void)hipFree(t->atab_T); (void)hipFree(t->atab_vec); (void)hipFree(t->atab_idx); }
     t->atab_T = nT; t->atab_vec = nvec; t->atab_idx = nidx; t->atab_count = K;

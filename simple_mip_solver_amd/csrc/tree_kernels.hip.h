@@ -191,6 +191,27 @@ __global__ __launch_bounds__(256) void unpack_nodes(PackArgs g) {
     for (int j = threadIdx.x; j < g.nvs; j += 256) g.pool_v[s * g.nvs + j] = v[j];
 }
 
+// bounds and basis of pool rows without cut rows as dense arrays over the shared rows only (the re-anchoring
+// launch of a tree with cut rounds: its pool keeps n + mstride basis codes per node)
+struct PlainGatherArgs {
+    int n, m, nvs_pool, count;
+    const int32_t *slot;
+    const double *pool_l, *pool_u;
+    const int8_t *pool_v;
+    double *l, *u;      // count x n
+    int8_t *v;          // count x (n + m)
+};
+__global__ __launch_bounds__(256) void gather_plain_nodes(PlainGatherArgs g) {
+    const int k = blockIdx.x;
+    if (k >= g.count) return;
+    const size_t s = (size_t)g.slot[k];
+    for (int j = threadIdx.x; j < g.n; j += 256) {
+        g.l[(size_t)k * g.n + j] = g.pool_l[s * g.n + j];
+        g.u[(size_t)k * g.n + j] = g.pool_u[s * g.n + j];
+    }
+    for (int j = threadIdx.x; j < g.n + g.m; j += 256) g.v[(size_t)k * (g.n + g.m) + j] = g.pool_v[s * g.nvs_pool + j];
+}
+
 // ---- cut rounds inside the frontier engine (reference base_node.py:137-230, :292-341) ------------
 // Per node of the batch a working copy of its cut list (ids into the engine's cut store, at most 64)
 // and a few counters; the kernels below are the host-free parts of _base_bound's loop: who is still
