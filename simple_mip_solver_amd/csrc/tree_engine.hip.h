@@ -1735,7 +1735,9 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
 int mipx_tree_reanchor(mipx_tree *t, int64_t max_nodes) {
     if (!t || max_nodes < 1) return MIPX_EINVAL;
     mipx_ctx *ctx = t->ctx;
-    if (!t->anchor_mode || !t->anchor_set)
+    // (with cut rounds a root that kept cut rows leaves no root anchor: the launch below then refactors
+    // from the slack basis)
+    if (!t->anchor_mode || (!t->anchor_set && !(t->cuts && t->evaluated > 0)))
         return fail(ctx, MIPX_EINVAL, "mipx_tree_reanchor: needs the anchor mode and a solved root");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(t->st3));

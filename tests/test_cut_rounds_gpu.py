@@ -287,6 +287,38 @@ def test_the_tableau_a_solve_ends_with_serves_the_cut_rounds(n, m, seed):
     prob.close()
 
 
+def test_reanchoring_with_cut_rounds():
+    """mipx_tree_reanchor on a tree with cut rounds: the open nodes that carry no cut row get the tableau of
+    their own basis as anchor, the others keep refactoring from the slack basis.  Same end as without:
+    a feasible integral solution, never better than the optimum of the run without cuts."""
+    for n, m, seed in ((20, 10, 1), (24, 10, 12)):
+        A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=seed)
+        ref = BranchAndBound(random_model(n, m, seed, 1.0), PseudoCostBranchNode, pseudo_costs={}, gomory_cuts=False,
+                             frontier_batch=1)
+        ref.solve()
+        ctx = _ffi.default_context()
+        prob = _ffi.Problem(ctx, A, b, c)
+        t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=8, pool_capacity=1 << 14,
+                      cut_params=dict(max_abs_coef=1000.0 * float(np.max(np.abs(A))), exact_tableau=0))
+        t.set_anchor_mode(True)
+        st = t.solve(mip_gap=1e-4, frontier_batch=8, max_steps=6)
+        rounds = 0
+        while st['status'] == 4 and rounds < 200:
+            t.reanchor(st['open_nodes'])
+            st = t.solve(mip_gap=1e-4, frontier_batch=8, max_steps=6)
+            rounds += 1
+        assert st['status'] == 1 and rounds >= 1
+        cs = t.cut_stats()
+        assert cs['total_cut_generation_iterations'] > 0
+        x = t.solution()
+        assert np.max(np.abs(x[ints] - np.round(x[ints]))) <= 1e-4
+        assert np.all(A @ x >= b - 1e-6) and np.all(x >= l - 1e-9) and np.all(x <= u + 1e-9)
+        assert isclose(float(c @ x), st['primal_bound'], abs_tol=1e-6)
+        assert ref.objective_value - 1e-6 <= st['primal_bound'] <= ref.objective_value + 2.0
+        t.close()
+        prob.close()
+
+
 def test_example_models_batched_with_cuts():
     for f, rec in sorted(TABLE.items()):
         path = os.path.join(HERE, 'golden', 'example_models', f)
