@@ -246,7 +246,7 @@ struct mipx_tree {
     bool child_pending = false;
     int32_t *h_pairs = nullptr; // pinned staging of the branching lists
     char *h_pres = nullptr;     // pinned mirror of the probe results [pp_obj | pp_status]
-    StepBuf buf[2];
+    StepBuf buf[3];   // a ring: up to three steps in flight (mipx_tree_solve)
     bool table_dirty = false, pipeline = true;
     int dive = 0;           // mipx_tree_set_dive: dive children in a row per node (0: off)
     bool pool_exhausted = false;
@@ -548,7 +548,7 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
     if (t->table_dirty) {  // pseudo-cost table as of the last finished step
         const size_t n = t->n;
         // (one copy from the pinned mirror; the previous upload has long been consumed: two steps ago)
-        char *ht = t->h_tab + (size_t)(t->steps & 1) * 17 * n;  // (two mirrors, alternating)
+        char *ht = t->h_tab + (size_t)(t->steps & 3) * 17 * n;  // (four mirrors in turn: three steps can be in flight)
         std::memcpy(ht, t->cost_l.data(), n * 8);
         std::memcpy(ht + n * 8, t->cost_r.data(), n * 8);
         std::memcpy(ht + 2 * n * 8, t->has_entry.data(), n);
@@ -1483,7 +1483,7 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
         t->d_cost_l = (double *)tab;
         t->d_cost_r = tab ? (double *)(tab + 8 * n) : nullptr;
         t->d_has = tab ? (uint8_t *)(tab + 16 * n) : nullptr;
-        if (hipHostMalloc((void **)&t->h_tab, 2 * 17 * n, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
+        if (hipHostMalloc((void **)&t->h_tab, 4 * 17 * n, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
     }
     if (branch_rule == 1) {
         rc |= dmalloc(ctx, &t->pp_l, pc * n); rc |= dmalloc(ctx, &t->pp_u, pc * n);
@@ -1609,9 +1609,18 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
         t->x_mip_gap = mip_gap; t->x_batch = frontier_batch; t->x_stop_flag = 0; t->x_done = false;
     }
     // With frontier batches > 1 the host half of step k (bookkeeping, children) overlaps the GPU
-    // half of step k+1, whose batch is popped before the children of step k exist.
+    // halves of steps k+1 and k+2, whose batches are popped before the children of step k exist: a ring
+    // of three step buffers.  Two steps queued ahead rather than one absorb a slow host half (the host
+    // half is about as long as the node-LP kernel; with one step ahead every hiccup of the host idled
+    // the GPU).
     const bool overlap = t->pipeline && frontier_batch > 1;
-    int cur = 0;
+    const int NBUF = overlap ? 3 : 1;
+    int head = 0, next = 0, nfl = 0;   // oldest step in flight, next free buffer, steps in flight
+    auto inflight_nodes = [&]() {
+        int64_t s = 0;
+        for (int k = 0; k < nfl; k++) s += t->buf[(head + k) % NBUF].B;
+        return s;
+    };
     // this rank's own limits: 1 = one that ends the search, 2 = its step quota is done, 0 = none
     auto limit_kind = [&](int64_t inflight) {
         if (t->unbounded || hook_stop || t->pool_exhausted) return 1;
@@ -1632,9 +1641,9 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
         int64_t want = frontier_batch;
         if (node_limit > 0 && node_limit - t->evaluated - inflight < want)
             want = node_limit - t->evaluated - inflight;
-        // every evaluated node may need pool rows for two children (four with the dive: the child
-        // solved in place branches too); a step in flight has the same claim.  When the pool
-        // cannot take a single node's children the search stops (status 4, stats.pool_exhausted).
+        // every evaluated node may need pool rows for two children per output level (the child solved
+        // in place branches too); the steps in flight have the same claim.  When the pool cannot take
+        // a single node's children the search stops (status 4, stats.pool_exhausted).
         const int64_t per = 2 * (1 + (int64_t)t->dive);
         const int64_t room = ((int64_t)t->free_slots.size() - per * inflight) / per;
         if (room < want) {
@@ -1647,22 +1656,23 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
         return (int)want;
     };
     for (;;) {
-    if (!tree_queue_empty(t) && !stop_now(0)) {
-        int rc = tree_launch(t, t->buf[cur], batch_size(0));
-        if (rc) return rc;
-        if (t->buf[cur].in_flight) steps++;
-    }
-    while (t->buf[cur].in_flight) {
-        // (steps that do not overlap run out of one buffer set: the cut loop's are large)
-        StepBuf &S = t->buf[cur], &N = overlap ? t->buf[1 - cur] : t->buf[cur];
-        if (overlap && !tree_queue_empty(t) && !stop_now(S.B)) {
-            const int want = batch_size(S.B);
-            if (want > 0) {
-                int rc = tree_launch(t, N, want);
-                if (rc) return rc;
-                if (N.in_flight) steps++;
-            }
+    for (;;) {
+        // queue steps ahead: the first unconditionally (an empty batch launches nothing), the others only
+        // with nodes to take
+        while (nfl < NBUF && !tree_queue_empty(t)) {
+            const int64_t fl = inflight_nodes();
+            if (stop_now(fl)) break;
+            const int want = batch_size(fl);
+            if (nfl > 0 && want <= 0) break;
+            StepBuf &N = t->buf[next];
+            int rc = tree_launch(t, N, want);
+            if (rc) return rc;
+            if (!N.in_flight) break;
+            steps++;
+            nfl++;
+            next = (next + 1) % NBUF;
         }
+        if (nfl == 0) break;
         if (t->hook && steps > 0 && steps % t->hook_every == 0 && steps != hooked_at) {
             hooked_at = steps;  // the GPU is busy with the queued steps while the ranks exchange
             if (t->hook(t->hook_user)) hook_stop = true;
@@ -1672,14 +1682,10 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
             const int xrc = x_tick(t, false);
             if (xrc) return xrc;
         }
-        int rc = tree_finish(t, S, overlap);
+        int rc = tree_finish(t, t->buf[head], overlap);
         if (rc) return rc;
-        if (!N.in_flight && !tree_queue_empty(t) && !stop_now(0)) {
-            rc = tree_launch(t, N, batch_size(0));
-            if (rc) return rc;
-            if (N.in_flight) steps++;
-        }
-        if (overlap) cur = 1 - cur;
+        head = (head + 1) % NBUF;
+        nfl--;
     }
     if (!t->comm || t->x_done) break;
     // Nothing in flight: out of open nodes, or at one of this rank's limits.  The other ranks may
