@@ -121,6 +121,34 @@ struct BucketQueue {
         if (count == 0 || i < cur) cur = i;
         count++;
     }
+    // A step's pushes in one go, in the given order (the queue ends up exactly as after the pushes one by
+    // one): a push lands in one of 10^5 buckets -- the header of its vector and the cache line of its tail
+    // are two misses -- so the headers are prefetched 16 items ahead and the tails 8 ahead.
+    void push_many(const Item *it, size_t cnt) {
+        if (cnt == 0) return;
+        if (!started) {   // (the scale comes from the first finite key: let the one-by-one path set it)
+            for (size_t k = 0; k < cnt; k++) push(it[k].key, it[k].id);
+            return;
+        }
+        size_t hi = 0;
+        for (size_t k = 0; k < cnt; k++) hi = std::max(hi, index(it[k].key));
+        if (hi >= tab.size()) tab.resize(hi + 1 + (hi >> 3));
+        constexpr size_t A = 16, Bd = 8;
+        for (size_t k = 0; k < cnt + A; k++) {
+            if (k < cnt) __builtin_prefetch(&tab[index(it[k].key)], 1);
+            if (k >= A - Bd && k - (A - Bd) < cnt) {
+                const std::vector<Item> &v = tab[index(it[k - (A - Bd)].key)];
+                if (!v.empty()) __builtin_prefetch(v.data() + v.size(), 1);
+            }
+            if (k >= A) {
+                const Item &e = it[k - A];
+                const size_t i = index(e.key);
+                tab[i].push_back(e);
+                if (count == 0 || i < cur) cur = i;
+                count++;
+            }
+        }
+    }
     bool empty() const { return count == 0; }
     size_t size() const { return count; }
     void settle() { while (cur < tab.size() && tab[cur].empty()) cur++; }
@@ -268,6 +296,7 @@ struct mipx_tree {
     BucketQueue bq;     // batched best-first search
     bool use_bq = false;
     std::vector<BucketQueue::Item> popped;
+    std::vector<BucketQueue::Item> pend;   // a step's pushes, handed to the bucket queue in one go (tree_finish)
     std::priority_queue<std::pair<double, int64_t>, std::vector<std::pair<double, int64_t>>,
                         std::greater<std::pair<double, int64_t>>> open_bounds;  // lazy, for DFS
     std::vector<uint8_t> is_open;
@@ -942,6 +971,9 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     // One evaluated node at output position pos.  level 0: a node of the batch (pool row
     // `slot`); level 1: a dive child.  Returns the id of the child that was solved in place by
     // the dive (to be evaluated next), or -1.
+    // (best first on the bucket queue: the pushes of the step are collected and queued together below)
+    const bool defer_push = t->use_bq && t->search == 0;
+    t->pend.clear();
     auto evaluate = [&](int64_t id, int pos, int32_t slot, int level, int depth, int32_t anchor, int &err) -> int64_t {
         t->evaluated++;
         const bool lp_feasible = status[pos] == 0 || status[pos] == 2;
@@ -984,6 +1016,8 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
                     const int64_t cid = (int64_t)t->nodes.size() - 1;
                     if (take_dive && dir == ddir[pos]) {
                         dive_child = cid;  // already solved: never enters the queue
+                    } else if (defer_push) {
+                        t->pend.push_back({c.key, cid});
                     } else {
                         tree_push(t, cid);
                     }
@@ -1003,8 +1037,18 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     };
     for (int k = 0; k < B; k++) {
         int err = MIPX_OK;
+        // (a chain reads ten result arrays at every level: more streams than the hardware prefetcher follows)
+        if ((k & 7) == 0 && k + 40 < B) {
+            for (int lv = 0; lv <= S.dive; lv++) {
+                const int pp = lv * B + k + 32;
+                __builtin_prefetch(&status[pp]); __builtin_prefetch(&obj[pp]); __builtin_prefetch(&mipf[pp]);
+                __builtin_prefetch(&bidx[pp]); __builtin_prefetch(&bval[pp]); __builtin_prefetch(&nprobe[pp]);
+                __builtin_prefetch(&npiv[pp]);
+                if (lv < S.dive) { __builtin_prefetch(&dvar[pp]); __builtin_prefetch(&ddir[pp]); __builtin_prefetch(&dval[pp]); }
+            }
+        }
         int64_t cid = evaluate(ids[k], k, slots[k], 0, S.recs[k].depth, S.recs[k].anchor, err);
-        if (err) return err;
+        if (err) { if (defer_push) t->bq.push_many(t->pend.data(), t->pend.size()); return err; }
         for (int level = 1; cid >= 0; level++) {   // the plunge: every dive child right after its parent
             const int32_t cslot = t->nodes[cid].slot;
             const int pos = level * B + k;
@@ -1012,12 +1056,13 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             t->dives++;
             t->pivots += npiv[pos];
             const int64_t next = evaluate(cid, pos, cslot, level, S.recs[k].depth + level, S.recs[k].anchor, err);
-            if (err) return err;
+            if (err) { if (defer_push) t->bq.push_many(t->pend.data(), t->pend.size()); return err; }
             dive_slots.push_back(cslot);  // its record row feeds its own children below
             t->nodes[cid].slot = -1;
             cid = next;
         }
     }
+    if (defer_push) t->bq.push_many(t->pend.data(), t->pend.size());
     if (incumbent_pos >= 0) {
         // the last improving node of the batch holds the incumbent
         if ((rc = tree_d2h(t, t->best_x.data(), S.d_x + (size_t)incumbent_pos * n, (size_t)n * 8))) return rc;
