@@ -1225,7 +1225,8 @@ int x_migrate(mipx_tree *t, int from, int to, int64_t amount) {
         HIP_TRY(ctx, hipMemcpy(meta.data(), msg + meta_off, meta.size() * 8, hipMemcpyDeviceToHost));
         const int64_t cnt = (int64_t)meta[0];
         if (cnt < 0 || cnt > amount) return fail(ctx, MIPX_EHIP, "tree: corrupt migration message");
-        if ((int64_t)t->free_slots.size() < cnt + 4 * (int64_t)t->max_batch)
+        // (room for the arrivals beside what the steps in flight -- up to three -- may still claim for children)
+        if ((int64_t)t->free_slots.size() < cnt + 3 * 2 * (1 + (int64_t)t->dive) * (int64_t)t->max_batch)
             return fail(ctx, MIPX_ENOMEM, "tree: node pool too small for the migrated nodes (raise pool_capacity)");
         for (int64_t k = 0; k < cnt; k++) {
             const double *mrec = meta.data() + 1 + 5 * k;
