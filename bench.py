@@ -88,9 +88,27 @@ def spawn_ranks(args):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    # rank 0's stdout is drained by a thread; the ranks are polled: the first one that exits non-zero takes
+    # the others down with it (a rank that died would otherwise leave its peers in the next all-gather)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            time.sleep(2.0)   # (let the ranks that were told -- MIPX_EPEER -- print their own errors)
+            for r, p in enumerate(procs):
+                if p.poll() is None:
+                    p.kill()
+            codes = [p.wait() for p in procs]
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(b''.join(chunks).decode())
     sys.stdout.flush()
     if any(codes):
         sys.stderr.write(f'bench.py: rank exit codes {codes}\n')

@@ -40,6 +40,7 @@ extern "C" {
 #define MIPX_ETOOBIG -4   /* (m, n) exceeds what the on-chip tableau kernels support */
 #define MIPX_ENOMEM -5
 #define MIPX_EHOOK -6     /* a step hook asked mipx_tree_solve to stop */
+#define MIPX_EPEER -7     /* multi-GPU: another rank failed, the joint search was stopped */
 
 typedef struct mipx_ctx mipx_ctx;
 typedef struct mipx_problem mipx_problem;
@@ -374,6 +375,20 @@ int mipx_tree_set_trace(mipx_tree *t, int on);
 int64_t mipx_tree_trace(mipx_tree *t, int64_t capacity, int64_t *node_id, int32_t *lp_status,
                         int32_t *branch_var, double *objective);
 
+/* Test hooks of the cut rounds (mipx_tree_create_ex with cut parameters).  mipx_tree_trace_cuts: with
+ * the trace on, 8 ints per evaluated node in trace order -- cut rounds, iterations / number of GMICs
+ * created, added, removed (the per-node increments of BaseNode._base_bound's totals,
+ * base_node.py:215-222), the cut rows the node ends with; returns the number of nodes recorded.
+ * mipx_tree_peek_cuts: for the open nodes in the order of mipx_tree_peek_open their ids, cut counts, cut
+ * lists (max_nodes x mipx_tree_cut_rows_per_node ids into the cut store) and the basis codes of their cut
+ * rows (same shape); any may be NULL.  mipx_tree_cut_store: the cuts added so far (pi: count x n, pi0),
+ * returns the count. */
+int64_t mipx_tree_trace_cuts(mipx_tree *t, int64_t capacity, int32_t *counters);
+int64_t mipx_tree_peek_cuts(mipx_tree *t, int64_t max_nodes, int64_t *node_id, int32_t *ncut, int32_t *cut_ids,
+                            int8_t *cut_vstat);
+int64_t mipx_tree_cut_store(mipx_tree *t, int64_t capacity, double *pi, double *pi0);
+int mipx_tree_cut_rows_per_node(const mipx_tree *t);
+
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU: one process per GPU, open nodes sharded, a best-first queue per rank.
  * The reference is single-process (branch_and_bound.py:215-241): no counterpart.  The communicator
@@ -425,11 +440,15 @@ int mipx_tree_set_comm(mipx_tree *t, mipx_comm *c, int every_steps);
  * A record is mipx_exchange_record_len(n) doubles: [0] incumbent value, [1] dual bound of the shard,
  * [2] open nodes (queued + in flight), [3] stop flag, [4..7] evaluated / LPs / probes / pivots since
  * sharding, [8] 1 if the rank holds a solution for [0], [9] exchange number, [10] its frontier batch,
+ * [11] pool rows it can take from a donor, [12] the lowest bound among its nodes in flight (inf: none;
+ * [1] includes it: a shard's dual bound covers queued, in-flight and closed nodes),
  * [16..16+n) the solution, then 4 n pseudo-cost samples (sum_l, sum_r, times_l, times_r).
- * [3] stop flag: 1 a limit that ends the search, 2 the rank's step quota is done.
+ * [3] stop flag: 1 a limit that ends the search, 2 the rank's step quota is done, 3 the rank failed
+ * (it is returning an error: every other rank stops and returns MIPX_EPEER).
  * reason: 0 go on, 1 no open node anywhere, 2 a rank's limit, 3 global gap <= mip_gap, 4 every rank has
- * done its steps or run dry.
- * moves: n_moves triples (from rank, to rank, node records), in the order they are carried out. */
+ * done its steps or run dry, 5 a rank failed.
+ * moves: n_moves triples (from rank, to rank, node records), in the order they are carried out; a move
+ * never exceeds the room [11] its receiver reported. */
 typedef struct mipx_exchange_decision {
     double primal, dual, gap;
     int64_t sums[4], open_nodes;
@@ -439,6 +458,9 @@ typedef struct mipx_exchange_decision {
 int mipx_exchange_record_len(int n);
 int mipx_exchange_decide(int world, int n, const double *records, double mip_gap, int allow_migration,
                          mipx_exchange_decision *out);
+/* Test hook: the record this rank would post right now (mipx_exchange_record_len(n) doubles; callable
+ * from a step hook, i.e. with steps in flight). */
+int mipx_tree_exchange_record(mipx_tree *t, double *record);
 typedef struct mipx_tree_global_stats_t {
     double primal_bound, dual_bound, gap;   /* gap: -1 encodes None */
     int64_t evaluated_nodes;                /* ramp-up (replicated: counted once) + every rank's since sharding */

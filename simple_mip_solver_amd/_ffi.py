@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MIPX_LIB') or os.path.join(_HERE, 'csrc', 'libmipx.so
 
 MIPX_OK = 0
 ERRORS = {-1: 'MIPX_EINVAL', -2: 'MIPX_ENODEV', -3: 'MIPX_EHIP', -4: 'MIPX_ETOOBIG',
-          -5: 'MIPX_ENOMEM', -6: 'MIPX_EHOOK'}
+          -5: 'MIPX_ENOMEM', -6: 'MIPX_EHOOK', -7: 'MIPX_EPEER'}
 
 # every symbol include/mipx.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -24,6 +24,8 @@ SYMBOLS = [
     'mipx_tree_cut_stats', 'mipx_comm_unique_id', 'mipx_comm_create_rccl', 'mipx_comm_create_custom',
     'mipx_comm_destroy', 'mipx_comm_rank', 'mipx_comm_size', 'mipx_comm_allgather', 'mipx_comm_barrier',
     'mipx_tree_set_comm', 'mipx_tree_global_stats', 'mipx_exchange_record_len', 'mipx_exchange_decide',
+    'mipx_tree_exchange_record', 'mipx_tree_trace_cuts', 'mipx_tree_peek_cuts', 'mipx_tree_cut_store',
+    'mipx_tree_cut_rows_per_node',
     'mipx_dev_alloc', 'mipx_dev_free',
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
@@ -691,6 +693,14 @@ class Tree:
         self.problem.ctx.check(L.mipx_tree_set_comm(self._h, None if comm is None else comm._h, int(every_steps)),
                                'mipx_tree_set_comm')
 
+    def exchange_record(self):
+        """The record this rank would post right now (mipx_tree_exchange_record; needs set_comm)."""
+        r = np.zeros(exchange_record_len(self.problem.n))
+        L = lib()
+        L.mipx_tree_exchange_record.argtypes = [_vp, _vp]
+        self.problem.ctx.check(L.mipx_tree_exchange_record(self._h, _ptr(r)), 'mipx_tree_exchange_record')
+        return r
+
     def global_stats(self):
         st = GlobalStats()
         L = lib()
@@ -780,6 +790,45 @@ class Tree:
         bv = np.zeros(k, np.int32); obj = np.zeros(k)
         lib().mipx_tree_trace(self._h, k, _ptr(ids), _ptr(st), _ptr(bv), _ptr(obj))
         return dict(node_id=ids, status=st, branch_var=bv, objective=obj)
+
+    def trace_cuts(self):
+        """(nodes, 8) per evaluated node in trace order: cut rounds, iterations / number of GMICs created,
+        added, removed, cut rows at the end (mipx_tree_trace_cuts)."""
+        L = lib()
+        L.mipx_tree_trace_cuts.argtypes = [_vp, C.c_int64, _vp]
+        L.mipx_tree_trace_cuts.restype = C.c_int64
+        k = L.mipx_tree_trace_cuts(self._h, 0, None)
+        out = np.zeros((max(k, 0), 8), np.int32)
+        L.mipx_tree_trace_cuts(self._h, k, _ptr(out))
+        return out
+
+    def peek_cuts(self, max_nodes):
+        """(node ids, cut counts, cut lists, basis codes of the cut rows) of the open nodes, in the order
+        of peek_open (mipx_tree_peek_cuts)."""
+        L = lib()
+        L.mipx_tree_peek_cuts.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, _vp]
+        L.mipx_tree_peek_cuts.restype = C.c_int64
+        L.mipx_tree_cut_rows_per_node.argtypes = [_vp]
+        kc = max(0, L.mipx_tree_cut_rows_per_node(self._h))
+        ids = np.zeros(max_nodes, np.int64); ncut = np.zeros(max_nodes, np.int32)
+        lists = np.zeros((max_nodes, max(kc, 1)), np.int32); codes = np.zeros((max_nodes, max(kc, 1)), np.int8)
+        k = L.mipx_tree_peek_cuts(self._h, int(max_nodes), _ptr(ids), _ptr(ncut), _ptr(lists), _ptr(codes))
+        if k < 0:
+            self.problem.ctx.check(int(k), 'mipx_tree_peek_cuts')
+        return ids[:k], ncut[:k], lists[:k], codes[:k]
+
+    def cut_store(self):
+        """(pi, pi0) of every cut added so far (mipx_tree_cut_store)."""
+        L = lib()
+        L.mipx_tree_cut_store.argtypes = [_vp, C.c_int64, _vp, _vp]
+        L.mipx_tree_cut_store.restype = C.c_int64
+        k = L.mipx_tree_cut_store(self._h, 0, None, None)
+        if k < 0:
+            self.problem.ctx.check(int(k), 'mipx_tree_cut_store')
+        pi = np.zeros((k, self.problem.n)); pi0 = np.zeros(k)
+        if k:
+            L.mipx_tree_cut_store(self._h, k, _ptr(pi), _ptr(pi0))
+        return pi, pi0
 
     def close(self):
         if getattr(self, '_h', None) and getattr(self.problem, '_h', None):

@@ -249,6 +249,7 @@ struct StepBuf {
     bool scored_once = false;  // K4 ran on this step (the first run's request counter was zeroed by K1)
     int B = 0;
     bool in_flight = false;
+    double inflight_min = std::numeric_limits<double>::infinity();   // lowest inherited bound of the batch (exchange record)
 };
 
 struct mipx_tree {
@@ -314,13 +315,17 @@ struct mipx_tree {
     std::vector<int64_t> tr_id;
     std::vector<int32_t> tr_status, tr_bidx;
     std::vector<double> tr_obj;
+    std::vector<int32_t> tr_cuts;   // cut rounds: 8 per evaluated node (rounds, the six GMIC counters, cut rows it ends with)
     bool trace = false;
     bool anchor_mode = false, anchor_set = false;
     // multi-GPU exchange (mipx_tree_set_comm)
     mipx_comm *comm = nullptr;
     int x_every = 0;
     bool x_done = false;             // the ranks agreed to stop (set by an applied exchange)
-    int x_stop_flag = 0;             // this rank hit one of its own limits
+    bool x_fatal = false;            // ... because a rank failed (reason 5)
+    bool child_recorded = false;     // ev_child has been recorded at least once
+    int fault_step = 0;              // MIPX_FAULT_STEP (tests): the step whose host half fails
+    int x_stop_flag = 0;             // this rank hit one of its own limits (3: it failed)
     int64_t x_rounds = 0;            // exchanges applied
     int x_batch = 1;                 // frontier batch of the running solve (what "cannot fill a batch" means)
     double x_mip_gap = 0.0;
@@ -520,6 +525,10 @@ void pc_update(mipx_tree *t, int var, int dir, int lp_status, double objective, 
         if (bc < 0) bc = 0;
         cost = (cost * (double)times + bc / variable_change) / (double)(times + 1);
         if (t->comm) t->pc_own[(dir ? n : 0) + (size_t)var] += bc / variable_change;   // this rank's samples, in sum form
+    } else if (t->comm) {
+        // a sample that counts without a cost leaves the mean where it is (pseudo_cost.py:97-100): in
+        // sum form it weighs in with the current mean, so that sum / times reproduces the recurrence
+        t->pc_own[(dir ? n : 0) + (size_t)var] += cost;
     }
     times += 1;
     if (t->comm) t->pc_own[(dir ? 3 * n : 2 * n) + (size_t)var] += 1.0;
@@ -540,6 +549,7 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
     S.recs.clear();
     S.B = 0;
     S.in_flight = false;
+    S.inflight_min = std::numeric_limits<double>::infinity();
     auto take = [&](int64_t id) {
         if (t->search != 0) t->is_open[id] = 0;
         NodeRec &nd = t->nodes[id];
@@ -553,6 +563,7 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
         ids.push_back(id);
         slots.push_back(slot);
         S.recs.push_back(nd);
+        S.inflight_min = std::fmin(S.inflight_min, nd.dual_bound);
         { const int64_t age = t->steps + 1 - nd.born; t->age_hist[age < 1 ? 0 : age > 7 ? 7 : age]++; t->depth_sum += nd.depth; }
     };
     if (t->use_bq) {
@@ -762,6 +773,9 @@ int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
     for (int k = 0; k < B; k++) {
         for (int f = 0; f < 7; f++) t->cut_totals[f] += S.h_cs[4 + (size_t)f * MB + k];
         t->cut_totals[7] += S.h_cs[4 + 8 * MB + k];
+        if (t->trace) {
+            for (int f = 0; f < 8; f++) t->tr_cuts.push_back(S.h_cs[4 + (size_t)f * MB + k]);
+        }
     }
     return MIPX_OK;
 }
@@ -1121,6 +1135,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         if (overlapped) {
             HIP_TRY(ctx, hipEventRecord(t->ev_child, t->st3));
             t->child_pending = true;
+            t->child_recorded = true;
         } else {
             HIP_TRY(ctx, hipStreamSynchronize(st));
         }
@@ -1147,10 +1162,13 @@ void x_fill_record(mipx_tree *t) {
     std::vector<double> &r = t->x_rec;
     r.assign(x_rec_len(t), 0.0);
     int64_t inflight = 0;
+    // the nodes popped into the steps in flight are neither queued nor closed: their bounds (the lowest
+    // of the shard under best first) count, or the shard would report a dual bound it has not proved
+    double inflight_min = std::numeric_limits<double>::infinity();
     for (const StepBuf &S : t->buf)
-        if (S.in_flight) inflight += S.B;
+        if (S.in_flight) { inflight += S.B; inflight_min = std::fmin(inflight_min, S.inflight_min); }
     r[0] = t->primal;
-    r[1] = tree_dual_bound(t);
+    r[1] = std::fmin(tree_dual_bound(t), inflight_min);
     r[2] = (double)(tree_open_count(t) + inflight);
     r[3] = (double)t->x_stop_flag;
     r[4] = (double)(t->evaluated - t->ramp[0]);
@@ -1160,6 +1178,14 @@ void x_fill_record(mipx_tree *t) {
     r[8] = t->have_x ? 1.0 : 0.0;
     r[9] = (double)t->x_rounds;
     r[10] = (double)t->x_batch;
+    // pool rows this rank can take from a donor: what is free beyond the children the steps in flight
+    // (up to three) and the steps until the record is applied may still claim
+    {
+        const int64_t per = 2 * (1 + (int64_t)t->dive) * (int64_t)t->max_batch;
+        const int64_t room = (int64_t)t->free_slots.size() - (3 + (int64_t)t->x_every) * per;
+        r[11] = (double)(room > 0 ? room : 0);
+    }
+    r[12] = inflight_min;
     if (t->have_x) std::memcpy(r.data() + kRecHead, t->best_x.data(), n * 8);
     std::memcpy(r.data() + kRecHead + n, t->pc_own.data(), 4 * n * 8);
 }
@@ -1185,6 +1211,10 @@ int x_migrate(mipx_tree *t, int from, int to, int64_t amount) {
     mipx::PackArgs pa;
     pa.n = (int)n; pa.nvs = (int)nvs; pa.rowbytes = rowbytes; pa.slot = d_slots;
     pa.pool_l = t->pool_l; pa.pool_u = t->pool_u; pa.pool_v = t->pool_v; pa.msg = msg;
+    // the child records of the last finished step may still be in the making on st3: the donor must not
+    // pack rows before they are written, the receiver must not overwrite the parents' rows (free again
+    // on the host) before they have been read
+    if (t->child_recorded) HIP_TRY(ctx, hipStreamWaitEvent(t->st2, t->ev_child, 0));
     if (me == from) {
         const int64_t have = tree_open_count(t);
         const int64_t give = std::max<int64_t>(0, std::min<int64_t>(amount, (have - t->x_batch) / 2));
@@ -1225,8 +1255,9 @@ int x_migrate(mipx_tree *t, int from, int to, int64_t amount) {
         HIP_TRY(ctx, hipMemcpy(meta.data(), msg + meta_off, meta.size() * 8, hipMemcpyDeviceToHost));
         const int64_t cnt = (int64_t)meta[0];
         if (cnt < 0 || cnt > amount) return fail(ctx, MIPX_EHIP, "tree: corrupt migration message");
-        // (room for the arrivals beside what the steps in flight -- up to three -- may still claim for children)
-        if ((int64_t)t->free_slots.size() < cnt + 3 * 2 * (1 + (int64_t)t->dive) * (int64_t)t->max_batch)
+        // (the amount was capped by the room this rank reported in its record -- x_decide -- which left the
+        // claims of the steps in flight aside; batch_size() keeps later steps within what is left)
+        if ((int64_t)t->free_slots.size() < cnt)
             return fail(ctx, MIPX_ENOMEM, "tree: node pool too small for the migrated nodes (raise pool_capacity)");
         for (int64_t k = 0; k < cnt; k++) {
             const double *mrec = meta.data() + 1 + 5 * k;
@@ -1267,7 +1298,7 @@ void x_decide(int W, int n, const double *records, double mip_gap, bool allow_mi
     // stop flags: 1 = a limit that ends the search for everybody (node_limit, max_seconds, unbounded,
     // a full pool); 2 = this rank has done the steps it was asked for (max_steps is a per-rank quota:
     // the others finish theirs)
-    bool any_stop = false, all_finished = true;
+    bool any_stop = false, all_finished = true, any_fatal = false;
     for (int r = 0; r < W; r++) {
         const double *q = rec(r);
         if (q[0] < best) best = q[0];
@@ -1275,6 +1306,7 @@ void x_decide(int W, int n, const double *records, double mip_gap, bool allow_mi
         sums[0] += (int64_t)q[4]; sums[1] += (int64_t)q[5]; sums[2] += (int64_t)q[6]; sums[3] += (int64_t)q[7];
         sums[4] += (int64_t)q[2];
         any_stop |= q[3] == 1.0;
+        any_fatal |= q[3] == 3.0;
         all_finished &= q[3] == 2.0 || q[2] == 0.0;
     }
     for (int r = 0; r < W && who < 0; r++)
@@ -1288,21 +1320,27 @@ void x_decide(int W, int n, const double *records, double mip_gap, bool allow_mi
     out->primal = best; out->dual = dual; out->gap = gap; out->incumbent_rank = who;
     for (int k = 0; k < 4; k++) out->sums[k] = sums[k];
     out->open_nodes = sums[4];
-    out->reason = sums[4] == 0 ? 1 : any_stop ? 2 : (gap >= 0 && gap <= mip_gap) ? 3 : all_finished ? 4 : 0;
+    out->reason = any_fatal ? 5 : sums[4] == 0 ? 1 : any_stop ? 2 : (gap >= 0 && gap <= mip_gap) ? 3 : all_finished ? 4 : 0;
     out->done = out->reason != 0;
     out->n_moves = 0;
     // migration: a rank that cannot fill a batch gets half the surplus of the fullest rank
     if (!out->done && allow_migration && W > 1) {
-        std::vector<int64_t> open((size_t)W), low((size_t)W);
-        for (int r = 0; r < W; r++) { open[(size_t)r] = (int64_t)rec(r)[2]; low[(size_t)r] = std::max<int64_t>(1, (int64_t)rec(r)[10]); }
+        std::vector<int64_t> open((size_t)W), low((size_t)W), room((size_t)W);
+        for (int r = 0; r < W; r++) {
+            open[(size_t)r] = (int64_t)rec(r)[2]; low[(size_t)r] = std::max<int64_t>(1, (int64_t)rec(r)[10]);
+            room[(size_t)r] = (int64_t)rec(r)[11];
+        }
         for (int d = 0; d < W && out->n_moves < 64; d++) {
             if (open[(size_t)d] >= low[(size_t)d]) continue;
             int src = 0;
             for (int r = 1; r < W; r++)
                 if (open[(size_t)r] > open[(size_t)src]) src = r;
             if (src == d || open[(size_t)src] < 2 * low[(size_t)src]) continue;
-            const int64_t amount = std::min<int64_t>((open[(size_t)src] - open[(size_t)d]) / 2, kMaxMigrate);
+            // (never more than the receiver said it has room for: it cannot refuse once the donor has sent)
+            const int64_t amount = std::min<int64_t>(std::min<int64_t>((open[(size_t)src] - open[(size_t)d]) / 2, kMaxMigrate),
+                                                     room[(size_t)d]);
             if (amount <= 0) continue;
+            room[(size_t)d] -= amount;
             int32_t *mv = out->moves + 3 * out->n_moves++;
             mv[0] = src; mv[1] = d; mv[2] = (int32_t)amount;
             open[(size_t)src] -= amount;
@@ -1358,8 +1396,9 @@ int x_apply(mipx_tree *t, const char *gathered, bool last) {
     }
     t->x_rounds++;
     if (last) return MIPX_OK;
-    if (D.done) {   // every rank idle, a rank's limit, or the global gap: the same on every rank
+    if (D.done) {   // every rank idle, a rank's limit, the global gap, or a rank that failed: the same on every rank
         t->x_done = true;
+        t->x_fatal = D.reason == 5;
         return MIPX_OK;
     }
     for (int k = 0; k < D.n_moves; k++) {
@@ -1398,6 +1437,28 @@ int x_close(mipx_tree *t) {
     if ((rc = comm_post(c, t->x_rec.data(), x_rec_len(t) * 8))) return rc;
     if ((rc = comm_collect(c, &g))) return rc;
     return x_apply(t, g, true);
+}
+
+// This rank is about to return an error from the step loop: tell the others, or they would wait for it
+// in the next all-gather for ever.  The sequence of all-gathers stays aligned: what was posted is
+// collected and applied, a record with the fatal flag follows (every rank that applies it stops, reason
+// 5), then the closing exchange the others run.  Best effort: an error in here is dropped (the rank is
+// failing already); a failure inside a migration's send / recv cannot be announced this way.
+void x_fail(mipx_tree *t) {
+    mipx_comm *c = t->comm;
+    const char *g = nullptr;
+    t->x_stop_flag = 3;
+    if (c->pending) {
+        if (comm_collect(c, &g)) return;
+        if (x_apply(t, g, false)) return;
+    }
+    if (!t->x_done) {
+        x_fill_record(t);
+        if (comm_post(c, t->x_rec.data(), x_rec_len(t) * 8)) return;
+        if (comm_collect(c, &g)) return;
+        if (x_apply(t, g, false)) return;
+    }
+    if (t->x_done) (void)x_close(t);
 }
 
 }  // namespace
@@ -1652,8 +1713,14 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
     int64_t steps = 0, hooked_at = 0, xchg_at = 0;
     bool hook_stop = false;
     if (t->comm) {
-        t->x_mip_gap = mip_gap; t->x_batch = frontier_batch; t->x_stop_flag = 0; t->x_done = false;
+        t->x_mip_gap = mip_gap; t->x_batch = frontier_batch; t->x_stop_flag = 0; t->x_done = false; t->x_fatal = false;
     }
+    t->fault_step = std::getenv("MIPX_FAULT_STEP") ? std::atoi(std::getenv("MIPX_FAULT_STEP")) : 0;
+    // an error of this rank's own step loop: the peers are told before it returns (x_fail)
+    auto bail = [&](int rc) {
+        if (t->comm && !t->x_done) x_fail(t);
+        return rc;
+    };
     // With frontier batches > 1 the host half of step k (bookkeeping, children) overlaps the GPU
     // halves of steps k+1 and k+2, whose batches are popped before the children of step k exist: a ring
     // of three step buffers.  Two steps queued ahead rather than one absorb a slow host half (the host
@@ -1712,7 +1779,7 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
             if (nfl > 0 && want <= 0) break;
             StepBuf &N = t->buf[next];
             int rc = tree_launch(t, N, want);
-            if (rc) return rc;
+            if (rc) return bail(rc);
             if (!N.in_flight) break;
             steps++;
             nfl++;
@@ -1729,7 +1796,9 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
             if (xrc) return xrc;
         }
         int rc = tree_finish(t, t->buf[head], overlap);
-        if (rc) return rc;
+        if (rc == MIPX_OK && t->fault_step > 0 && t->steps >= t->fault_step)
+            rc = fail(ctx, MIPX_EHIP, "tree: injected fault (MIPX_FAULT_STEP)");
+        if (rc) return bail(rc);
         head = (head + 1) % NBUF;
         nfl--;
     }
@@ -1776,6 +1845,7 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
     else t->status = 4;
     if (out) mipx_tree_get_stats(t, out);
     if (hook_stop) return fail(ctx, MIPX_EHOOK, "mipx_tree_solve: stopped by the step hook");
+    if (t->comm && t->x_fatal) return fail(ctx, MIPX_EPEER, "mipx_tree_solve: another rank failed; the search was stopped");
     return MIPX_OK;
 }
 
@@ -1908,6 +1978,14 @@ int mipx_tree_get_stats(mipx_tree *t, mipx_tree_stats *out) {
 }
 
 int mipx_exchange_record_len(int n) { return n > 0 ? kRecHead + 5 * n : MIPX_EINVAL; }
+
+int mipx_tree_exchange_record(mipx_tree *t, double *record) {
+    if (!t || !record) return MIPX_EINVAL;
+    if (!t->comm) return fail(t->ctx, MIPX_EINVAL, "mipx_tree_exchange_record: no communicator attached");
+    x_fill_record(t);
+    std::memcpy(record, t->x_rec.data(), x_rec_len(t) * 8);
+    return MIPX_OK;
+}
 
 int mipx_exchange_decide(int world, int n, const double *records, double mip_gap, int allow_migration,
                          mipx_exchange_decision *out) {
@@ -2069,6 +2147,53 @@ int mipx_tree_keep_shard(mipx_tree *t, int rank, int world) {
     if (rank != 0) t->closed_min = std::numeric_limits<double>::infinity();  // counted once, on rank 0
     return MIPX_OK;
 }
+
+int64_t mipx_tree_trace_cuts(mipx_tree *t, int64_t capacity, int32_t *counters) {
+    if (!t) return MIPX_EINVAL;
+    const int64_t have = (int64_t)t->tr_cuts.size() / 8;
+    const int64_t k = have < capacity ? have : capacity;
+    if (counters && k > 0) std::memcpy(counters, t->tr_cuts.data(), (size_t)k * 8 * 4);
+    return have;
+}
+
+/* Test hooks of the cut rounds: the open nodes' ids, cut lists (ids into the cut store) and the basis
+ * codes of their cut rows, in the order of mipx_tree_peek_open; and the cut store itself. */
+int64_t mipx_tree_peek_cuts(mipx_tree *t, int64_t max_nodes, int64_t *node_id, int32_t *ncut, int32_t *cut_ids,
+                            int8_t *cut_vstat) {
+    if (!t || max_nodes < 0) return MIPX_EINVAL;
+    mipx_ctx *ctx = t->ctx;
+    if (hipStreamSynchronize(t->st3) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return MIPX_EHIP;
+    std::vector<int64_t> order;
+    tree_queue_ids(t, order);
+    const size_t n = t->n, m = t->m, nvs = n + (size_t)t->mrows, K = (size_t)t->kc;
+    int64_t k = 0;
+    for (size_t pos = 0; pos < order.size() && k < max_nodes; pos++, k++) {
+        const NodeRec &nd = t->nodes[order[pos]];
+        const size_t s = (size_t)nd.slot;
+        if (node_id) node_id[k] = order[pos];
+        if (ncut) ncut[k] = t->cuts ? nd.ncut : 0;
+        if (t->cuts && K > 0) {
+            if (cut_ids && hipMemcpy(cut_ids + k * K, t->pool_ids + s * K, K * 4, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
+            if (cut_vstat && hipMemcpy(cut_vstat + k * K, t->pool_v + s * nvs + n + m, K, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
+        }
+    }
+    return k;
+}
+
+int64_t mipx_tree_cut_store(mipx_tree *t, int64_t capacity, double *pi, double *pi0) {
+    if (!t) return MIPX_EINVAL;
+    if (!t->cuts) return 0;
+    if (hipStreamSynchronize(t->ctx->stream) != hipSuccess) return MIPX_EHIP;
+    int32_t cnt = 0;
+    if (hipMemcpy(&cnt, t->store_count, 4, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
+    int64_t have = cnt < t->store_cap ? cnt : t->store_cap;
+    const int64_t k = have < capacity ? have : capacity;
+    if (pi && k > 0 && hipMemcpy(pi, t->store_pi, (size_t)k * t->n * 8, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
+    if (pi0 && k > 0 && hipMemcpy(pi0, t->store_pi0, (size_t)k * 8, hipMemcpyDeviceToHost) != hipSuccess) return MIPX_EHIP;
+    return have;
+}
+
+int mipx_tree_cut_rows_per_node(const mipx_tree *t) { return t ? t->kc : MIPX_EINVAL; }
 
 int64_t mipx_tree_trace(mipx_tree *t, int64_t capacity, int64_t *node_id, int32_t *lp_status,
                         int32_t *branch_var, double *objective) {

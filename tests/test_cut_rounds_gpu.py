@@ -335,3 +335,150 @@ def test_cut_mode_limits():
     bb = BranchAndBound(random_model(300, 150, 0), PseudoCostBranchNode, pseudo_costs={}, frontier_batch=4)
     with pytest.raises(_ffi.MipxError, match='MIPX_ETOOBIG'):
         bb.solve()
+
+
+# ---- (4) one step of the BATCHED cut mode, node by node through the oracle ---------------------------
+def replay_cut_loop(oracle, A, b, c, l, u, ints, first, rows_pi, rows_pi0, vstat, params):
+    """BaseNode._base_bound's loop (base_node.py:196-203, :292-341) for one node on oracle pieces only:
+    `first` is the node's LP result, rows_pi / rows_pi0 the cut rows it carries, vstat its basis over
+    n + m + cuts.  Returns (8 counters like mipx_tree_trace_cuts, status, objective)."""
+    m, n = A.shape
+    rows_pi, rows_pi0 = [np.asarray(p) for p in rows_pi], list(rows_pi0)
+    cnt = dict(rounds=0, it_created=0, n_created=0, it_added=0, n_added=0, it_removed=0, n_removed=0)
+    pool_pi, pool_pi0 = [], []
+    r, stalled = first, False
+    vstat = np.asarray(vstat, np.int8).copy()
+
+    def materialised():
+        Ak = np.vstack([A] + [p[None] for p in rows_pi]) if rows_pi else A
+        bk = np.concatenate([b, rows_pi0]) if rows_pi else b
+        return Ak, bk
+    while True:
+        feas = r['status'] in (0, 2)
+        obj = r['obj'] if feas else INF
+        if not (feas and not oracle.mip_feasible(ints, r['x']) and not stalled and
+                cnt['rounds'] < params['max_rounds'] and obj < INF):
+            break
+        cnt['rounds'] += 1
+        before = obj
+        changed = False
+        if rows_pi:     # _remove_slack_cuts: rows whose dual is exactly 0 leave, the basis is compacted
+            y = r['y']
+            keep = [k for k in range(len(rows_pi)) if y[m + k] != 0.0]
+            if len(keep) < len(rows_pi):
+                cnt['it_removed'] += 1; cnt['n_removed'] += len(rows_pi) - len(keep)
+                vstat = np.concatenate([vstat[:n + m], vstat[n + m:][keep]])
+                rows_pi = [rows_pi[k] for k in keep]; rows_pi0 = [rows_pi0[k] for k in keep]
+                changed = True
+        Ak, bk = materialised()
+        x = np.maximum(r['x'], 0)
+        g = oracle.gomory(Ak, bk, c, l, u, vstat, x, ints, params['max_term'])
+        if len(g['row_idx']):
+            cnt['it_created'] += 1; cnt['n_created'] += len(g['row_idx'])
+        pool_pi += list(g['safe_pi']); pool_pi0 += list(g['safe_pi0'])
+        added, _, _ = oracle.select_cuts(np.array(pool_pi).reshape(len(pool_pi0), n), np.array(pool_pi0), x, 1000000,
+                                         params['min_cut_depth'], params['cos_parallel'], params['max_abs_coef'])
+        if len(added):
+            cnt['it_added'] += 1; cnt['n_added'] += len(added)
+            for i in added:
+                rows_pi.append(pool_pi[i]); rows_pi0.append(pool_pi0[i])
+            vstat = np.concatenate([vstat, np.ones(len(added), np.int8)])   # a new row enters with its slack basic
+            gone = set(int(i) for i in added)
+            pool_pi = [p for i, p in enumerate(pool_pi) if i not in gone]
+            pool_pi0 = [p for i, p in enumerate(pool_pi0) if i not in gone]
+            changed = True
+        if changed:     # (an unchanged LP is not re-solved by the engine: same objective, it stalls either way)
+            Ak, bk = materialised()
+            r = oracle.lp_solve(Ak, bk, c, l, u, vstat)
+            vstat = r['vstat']
+        new = r['obj'] if r['status'] in (0, 2) else INF
+        with np.errstate(invalid='ignore', divide='ignore'):
+            if abs(before - new) / abs(before) < params['progress_tol']:
+                stalled = True
+    return ([cnt['rounds'], cnt['it_created'], cnt['n_created'], cnt['it_added'], cnt['n_added'], cnt['it_removed'],
+             cnt['n_removed'], len(rows_pi)], r['status'], r['obj'] if r['status'] in (0, 2) else INF)
+
+
+@pytest.mark.parametrize('n,m,seed,density,boxed,target,MB', [
+    (256, 128, 0, 1.0, True, 400, 1024),     # BASELINE C4: the bench's family (cuts created, none added)
+    (256, 128, 1, 1.0, False, 200, 512),     # 256 x 128 where the reference's rules DO add cuts
+    (64, 32, 5, 1.0, False, 200, 512),       # nodes that carry, gain and lose cut rows
+    (64, 32, 2, 0.25, True, 200, 512)])
+def test_batched_cut_mode_step_replays_through_the_oracle(n, m, seed, density, boxed, target, MB, gpu_ctx, oracle):
+    """The configuration bench.py measures C4 on -- exact_tableau=0 (K2 reads the tableau a solve ends
+    with), anchored, re-anchored, a whole frontier per step -- checked at step level: every node of one
+    step against the oracle's replay of BaseNode._base_bound on the same record (bounds, basis, the cut
+    rows it carries): cut rounds, GMICs created / added / removed, cut rows kept, final LP status, final
+    objective to 1e-9."""
+    import math
+    A, b, c, l, u, ints = random_dense_milp_arrays(n, m, density=density, seed=seed)
+    if not boxed:
+        u = np.full(n, INF)
+    prob = _ffi.Problem(gpu_ctx, A, b, c)
+    params = dict(max_rounds=10, progress_tol=1e-4, min_cut_depth=1e-8, cos_parallel=math.cos(math.radians(10)),
+                  max_abs_coef=1000.0 * float(np.max(np.abs(A))), max_term=1e3)
+    t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=MB, pool_capacity=1 << 15,
+                  cut_params=dict(max_abs_coef=params['max_abs_coef'], exact_tableau=0))
+    t.set_anchor_mode(True)
+    st = t.stats()
+    while st['open_nodes'] < target:
+        st = t.solve(mip_gap=0.0, frontier_batch=64, max_steps=1)
+        assert st['status'] == 4
+    t.reanchor(st['open_nodes'])
+    N = st['open_nodes']
+    assert N <= MB
+    L, U, V, _ = t.peek_open(N)
+    ids, ncut, lists, codes = t.peek_cuts(N)
+    sel = t.peek_anchors(N)
+    atab = t.anchor_table()
+    store_pi, store_pi0 = t.cut_store()
+    assert len(ids) == N and np.all(sel[ncut > 0] == -1)
+    t.set_trace(True)
+    t.solve(mip_gap=0.0, frontier_batch=MB, max_steps=1)
+    tr, tc = t.trace(), t.trace_cuts()
+    assert len(tr['node_id']) == len(tc) > 0 and set(tr['node_id']) <= set(ids.tolist())
+    where = {int(i): k for k, i in enumerate(ids)}
+    # first LPs of the nodes without cut rows: from the anchor their record names (own table entry, else
+    # the root's tableau -- which exists only if the root kept no cut row)
+    root = oracle.lp_solve(A, b, c, l, u)
+    root_kept_rows = store_pi0.size > 0 and replay_cut_loop(oracle, A, b, c, l, u, ints, root, [], [], root['vstat'],
+                                                            params)[0][7] > 0
+    plain = [where[int(i)] for i in tr['node_id'] if ncut[where[int(i)]] == 0]
+    zero = np.zeros(n)
+    import contextlib
+    cm = contextlib.nullcontext()
+    if not root_kept_rows:
+        # (the root's final basis: its LP optimum -- rounds that add no row leave it alone)
+        cm = oracle.anchored(oracle.make_anchor(A, b, c, root['vstat']))
+    with cm:
+        fo = oracle.lp_solve_dive_batch(A, b, c, L[plain], U[plain], V[plain], -1, ints, zero, zero,
+                                        np.zeros(n, np.uint8), INF, anchor_table=atab,
+                                        anchor_sel=None if atab is None else sel[plain]) if plain else None
+    first = {}
+    for j, k in enumerate(plain):
+        first[k] = dict(status=int(fo['status'][j]), obj=float(fo['obj'][j]), x=fo['x'][j], vstat=fo['vstat'][j])
+    seen_rows = seen_added = seen_removed = 0
+    for pos, nid in enumerate(tr['node_id']):
+        k = where[int(nid)]
+        rp = [store_pi[i] for i in lists[k, :ncut[k]]]
+        rp0 = [store_pi0[i] for i in lists[k, :ncut[k]]]
+        vfull = np.concatenate([V[k], codes[k, :ncut[k]]])
+        if ncut[k] == 0:
+            f = first[k]
+        else:
+            Ak = np.vstack([A] + [p[None] for p in rp]); bk = np.concatenate([b, rp0])
+            f = oracle.lp_solve(Ak, bk, c, L[k], U[k], vfull)
+            vfull = f['vstat'] if f['status'] in (0, 2) else vfull
+        if ncut[k] == 0 and f['status'] in (0, 2):
+            vfull = f['vstat']
+        counters, status, obj = replay_cut_loop(oracle, A, b, c, L[k], U[k], ints, f, rp, rp0, vfull, params)
+        assert tr['status'][pos] == status, (pos, int(nid), tr['status'][pos], status)
+        assert tc[pos].tolist() == counters, (pos, int(nid), tc[pos].tolist(), counters)
+        if status in (0, 2):
+            assert isclose(tr['objective'][pos], obj, rel_tol=1e-9, abs_tol=1e-9), (pos, tr['objective'][pos], obj)
+        seen_rows += ncut[k] > 0; seen_added += counters[4]; seen_removed += counters[6]
+    assert tc[:, 2].sum() > 0                      # GMICs were created
+    if (n, boxed) != (256, True):                  # ... and on these shapes added, carried and dropped again
+        assert seen_added > 0 and seen_rows > 0
+    t.close()
+    prob.close()

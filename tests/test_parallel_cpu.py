@@ -21,12 +21,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INF = float('inf')
 
 
-def record(n, primal=INF, dual=-INF, open_nodes=0, stop=0, counts=(0, 0, 0, 0), x=None, batch=8, samples=None):
+def record(n, primal=INF, dual=-INF, open_nodes=0, stop=0, counts=(0, 0, 0, 0), x=None, batch=8, samples=None,
+           room=1 << 30):
     r = np.zeros(_ffi.exchange_record_len(n))
     r[0], r[1], r[2], r[3] = primal, dual, open_nodes, stop
     r[4:8] = counts
     r[8] = 0.0 if x is None else 1.0
     r[10] = batch
+    r[11] = room
+    r[12] = INF
     if x is not None:
         r[16:16 + n] = x
     if samples is not None:
@@ -82,6 +85,28 @@ def test_decision_rules():
     assert _ffi.exchange_decide(recs, n)['moves'] == []
     recs[0, 2] = 40000                                                     # a donation is capped
     assert _ffi.exchange_decide(recs, n)['moves'][0] == (0, 1, 4096)
+    # ... and never exceeds the room its receiver reported (the receiver cannot refuse after the send);
+    # a rank without room receives nothing
+    recs[1, 11], recs[2, 11] = 100, 0
+    assert _ffi.exchange_decide(recs, n)['moves'] == [(0, 1, 100)]
+    # a rank that is returning an error stops everybody (reason 5 outranks everything, no moves)
+    recs[3, 3] = 3.0
+    d = _ffi.exchange_decide(recs, n)
+    assert d['done'] and d['reason'] == 5 and d['moves'] == []
+    recs[:, 2] = 0
+    assert _ffi.exchange_decide(recs, n)['reason'] == 5
+
+
+def test_tail_of_the_search_is_not_a_closed_gap():
+    """A rank whose queue is empty while its last nodes are in flight reports THEIR bound ([12], folded
+    into [1] by the engine), not the value of its closed leaves: the gap of such records stays open."""
+    n = 3
+    # rank 0 holds the incumbent -9, queue empty, 64 nodes in flight with bounds down to -9.4
+    r0 = record(n, primal=-9.0, dual=-9.4, open_nodes=64, x=[1, 2, 3])
+    r0[12] = -9.4
+    r1 = record(n, primal=-9.0, dual=-9.0, open_nodes=0)
+    d = _ffi.exchange_decide(np.stack([r0, r1]), n, mip_gap=1e-4)
+    assert not d['done'] and d['dual'] == -9.4
 
 
 WORKER = textwrap.dedent('''
@@ -132,9 +157,15 @@ WORKER = textwrap.dedent('''
 ''')
 
 
+RENDEZVOUS_CLASH = ('address already in use', 'eaddrinuse', 'errno: 98')
+
+
 def run_two_ranks(script, timeout=300, extra_env=None):
+    """Two ranks under torch.distributed.run.  The free port is probed, not reserved, so a run is
+    repeated ONLY when its stderr shows a rendezvous clash on the port; any other failure -- a rank that
+    crashed, an assertion, a GPU fault -- is returned at once (a retry must not be able to hide it)."""
     res = None
-    for attempt in range(3):  # the free port is probed, not reserved: retry on a rendezvous clash
+    for attempt in range(3):
         with socket.socket() as s:
             s.bind(('127.0.0.1', 0))
             port = s.getsockname()[1]
@@ -143,8 +174,9 @@ def run_two_ranks(script, timeout=300, extra_env=None):
                               '--nproc-per-node=2', '--master-addr', '127.0.0.1', '--master-port',
                               str(port), str(script)], env=env, capture_output=True, text=True,
                              timeout=timeout)
-        if res.returncode == 0:
+        if res.returncode == 0 or not any(k in res.stderr.lower() for k in RENDEZVOUS_CLASH):
             break
+        sys.stderr.write(f'run_two_ranks: rendezvous clash on port {port} (attempt {attempt + 1}), stderr was:\n{res.stderr}\n')
     return res
 
 

@@ -81,6 +81,49 @@ def test_rccl_one_rank_collective_solve():
     assert abs(float(c @ x) - st['primal_bound']) < 1e-6 and abs(float(c @ xr) - ref['primal_bound']) < 1e-6
 
 
+def test_record_dual_bound_covers_the_steps_in_flight():
+    """The exchange record's dual bound ([1]) includes the nodes popped into the steps in flight ([12]):
+    read from a step hook (steps ARE in flight there) it never decreases and never exceeds the optimum,
+    also in the tail of the search where the queue is empty and the last nodes are being solved; and a
+    one-rank collective solve with an exchange at every step ends like the plain solve (the decision
+    'gap closed' is taken from those records)."""
+    from simple_mip_solver_amd import _ffi
+    from simple_mip_solver_amd.generators import random_dense_milp_arrays
+    ctx = _ffi.default_context()
+    comm = _ffi.Comm(ctx, 0, 1, allgather=lambda b: [b], send=lambda p, d: None, recv=lambda p, k: b'')
+    covered = 0
+    for seed in range(6):
+        n, m, B = 40, 16, 8
+        A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=seed)
+        prob = _ffi.Problem(ctx, A, b, c)
+        ref_t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=B, pool_capacity=1 << 15)
+        ref_t.set_anchor_mode(True); ref_t.set_dive(True)
+        ref = ref_t.solve(mip_gap=1e-4, frontier_batch=B)
+        assert ref['status'] == 1
+        t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=B, pool_capacity=1 << 15)
+        t.set_anchor_mode(True); t.set_dive(True)
+        t.solve(mip_gap=0.0, frontier_batch=B, max_steps=2)
+        t.keep_shard(0, 1)
+        t.set_comm(comm, 1)
+        seen = []
+        t.set_step_hook(lambda: seen.append(t.exchange_record()[[1, 2, 12]]) and False, 1)
+        st = t.solve(mip_gap=1e-4, frontier_batch=B)
+        t.set_step_hook(None)
+        assert st['status'] == 1 and abs(st['primal_bound'] - ref['primal_bound']) < 1e-9, (seed, st, ref)
+        seen = np.array(seen)
+        assert len(seen) > 3
+        assert np.all(np.diff(seen[:, 0]) >= 0), (seed, seen[:, 0])          # a proven bound never decreases
+        assert np.all(seen[:, 0] <= ref['primal_bound'] + 1e-9), (seed, seen[:, 0])
+        assert np.all(seen[:, 0] <= seen[:, 2])                               # [1] includes [12]
+        covered += int(np.sum(np.isfinite(seen[:, 2]) & (seen[:, 0] == seen[:, 2])))
+        # the merged pseudo-cost table of one rank is the table of the plain recurrence (a sample that counts
+        # without a cost -- an infeasible child -- weighs in with the mean)
+        own = t.pseudo_cost_arrays()
+        assert np.all(np.isfinite(own[0])) and np.all(own[2] >= 0)
+        t.set_comm(None)
+    assert covered > 0   # the in-flight nodes did hold the shard's bound at some exchange
+
+
 WORKER = textwrap.dedent('''
     import os, sys
     sys.path.insert(0, {root!r})
@@ -154,6 +197,20 @@ WORKER = textwrap.dedent('''
     steps_after = comm.allgather(np.array([st['steps'] - r2['steps'], st['status']], float))
     assert np.all(steps_after[:, 1] == 4) and steps_after[1, 0] <= 9 + 12, steps_after
     t.set_comm(None)
+
+    # --- a rank that fails tells the other: nobody is left waiting in an all-gather ---------------------
+    t = tree()
+    r3 = shard_and_attach(t, comm, B, exchange_every=2)
+    if rank == 1:
+        os.environ['MIPX_FAULT_STEP'] = str(t.stats()['steps'] + 3)
+    try:
+        t.solve(mip_gap=0.0, frontier_batch=B, max_steps=40)
+        raise SystemExit('rank %d: expected an error' % rank)
+    except _ffi.MipxError as e:
+        assert ('injected fault' in str(e)) if rank == 1 else ('MIPX_EPEER' in str(e) or 'another rank failed' in str(e)), str(e)
+    os.environ.pop('MIPX_FAULT_STEP', None)
+    t.set_comm(None)
+    comm.barrier()                                  # the all-gather sequence is still aligned
 
     # --- through the driver -----------------------------------------------------------------------
     make = lambda: MILPInstance(A=A, b=b, c=c, l=l, u=u, sense=['Min', '>='], integerIndices=ints, numVars=n)

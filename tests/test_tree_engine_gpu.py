@@ -347,7 +347,8 @@ def test_full_node_pool_stops_the_search_cleanly():
 
 @pytest.mark.parametrize('depth', [1, 4])
 @pytest.mark.parametrize('n,m,MB,K,target', [(64, 32, 1024, 200, 300), (300, 150, 256, 40, 60),
-                                             (256, 128, 1024, 300, 600)])   # (the last: bench.py's tile + anchor table + slots)
+                                             (256, 128, 1024, 300, 600),    # (bench.py's tile + anchor table + slots)
+                                             (1024, 512, 64, 16, 32)])      # (C5 at size: plunge + re-anchor on the HBM-streaming kernel)
 def test_reanchored_step_matches_the_oracle(n, m, MB, K, target, depth, oracle):
     """mipx_tree_reanchor: open nodes get the tableau of their warm-start basis as their own anchor.
     The table is what the oracle builds for the same bases (refactor-only from the root's tableau), a
