@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument('--highs-seconds', type=float, default=5.0, help='wall seconds of the HiGHS baseline B2 (0: skip)')
     ap.add_argument('--tto-seconds', type=float, default=5.0, help='time limit of the time-to-optimal leg (0: skip)')
     ap.add_argument('--others', type=int, default=1, choices=[0, 1], help='1: also measure C2, C4, C5 (config.others)')
+    ap.add_argument('--no-dive-leg', type=int, default=1, choices=[0, 1],
+                    help='1: also time the same region with --dive 0 (value_no_dive; one GPU only)')
     ap.add_argument('--exchange-every', type=int, default=5, help='steps between exchanges (N > 1)')
     ap.add_argument('--dive', type=int, default=8, choices=range(0, 9),
                     help='dive children solved in a row on the tableau a node\'s workgroup holds (mipx_tree_set_dive; 0: off)')
@@ -231,61 +233,131 @@ def highs_baseline(args, prob, A, b, c, sample):
                     'same node LPs the GPU solved (first %d of the sample)' % k}
 
 
-def time_to_optimal_leg(args, ctx, A, b, c, l, u, ints):
-    """The metric's second leg on its own 256 x 128 instance.  Pure best-first finds no incumbent here
-    in millions of nodes (round 1), the reference's depth-first node class does
-    (nodes/search/depth_first.py:16-28): depth-first in the engine, the plunge (--dive levels) on top."""
+GAP_MARKS = (0.01, 0.005, 0.0035, 0.003, 0.0025)
+
+
+def two_phase(ctx, A, b, c, l, u, ints, dive, dfs_seconds, limit, pool_log2, mip_gap=1e-4, marks=()):
+    """The reference's loop ends on current_gap <= mip_gap (branch_and_bound.py:199-229).  Two phases
+    on the engine: depth first (DepthFirstSearchNode semantics, nodes/search/depth_first.py:16-28)
+    until `dfs_seconds` have passed, for an incumbent; then best first on a fresh tree with that
+    incumbent installed as initial_primal_bound (branch_and_bound.py:121, :157), which lifts the dual
+    bound.  The gap of the run at any time is |best incumbent - proven dual bound| / |incumbent|
+    with the bounds of the phase in progress (both are bounds of the same problem).  Returns the
+    times at which the gap first fell below each of `marks`."""
     from simple_mip_solver_amd import _ffi
     p = _ffi.Problem(ctx, A, b, c)
-    Bt = 1024
-    t = _ffi.Tree(p, ints, l, u, branch_rule='pseudo cost', search_rule='depth first', max_batch=Bt,
+    inf = float('inf')
+    t0 = time.perf_counter()
+    reached = {}
+    nodes = 0
+
+    def note(s, extra_nodes=0):
+        g = s['gap']
+        for mk in marks:
+            if mk not in reached and 0 <= g <= mk:
+                reached[mk] = {'seconds': time.perf_counter() - t0, 'nodes': extra_nodes + s['evaluated_nodes'],
+                               'primal_bound': s['primal_bound'], 'dual_bound': s['dual_bound']}
+    t = _ffi.Tree(p, ints, l, u, branch_rule='pseudo cost', search_rule='depth first', max_batch=1024,
                   pool_capacity=1 << 21)
     t.set_anchor_mode(True)
-    depth = max(1, args.dive)
-    t.set_dive(depth)
-    t0 = time.perf_counter()
+    t.set_dive(max(1, dive))
     first, s = None, None
-    while time.perf_counter() - t0 < args.tto_seconds:
-        s = t.solve(mip_gap=1e-4, frontier_batch=Bt, max_steps=2 if first is None else 50)
-        if first is None and s['primal_bound'] < float('inf'):
+    while time.perf_counter() - t0 < dfs_seconds:
+        s = t.solve(mip_gap=mip_gap, frontier_batch=1024, max_steps=2 if first is None else 20)
+        if first is None and s['primal_bound'] < inf:
             first = {'seconds': time.perf_counter() - t0, 'nodes': s['evaluated_nodes'], 'objective': s['primal_bound']}
+        note(s)
         if s['status'] != 4:
             break
-    el = time.perf_counter() - t0
-    out = {'instance': f'{len(c)} vars x {len(b)} rows, seed {args.seed} (the metric\'s own instance)',
-           'search': f'PseudoCostBranchDepthFirstSearchNode semantics in the native engine, {Bt} nodes per step + in-place dive of depth {depth}',
-           'time_to_first_incumbent': first, 'status': _ffi.TREE_STATUS[s['status']],
-           'seconds': el, 'time_to_optimal': el if s['status'] == 1 else None,
-           'primal_bound': None if s['primal_bound'] == float('inf') else s['primal_bound'],
-           'dual_bound': s['dual_bound'], 'gap': None if s['gap'] < 0 else s['gap'], 'nodes': s['evaluated_nodes'],
-           'note': 'time_to_optimal is null unless the gap closed to 1e-4 inside the time limit'}
+    phase1 = {'seconds': time.perf_counter() - t0, 'nodes': s['evaluated_nodes'],
+              'primal_bound': None if s['primal_bound'] == inf else s['primal_bound'], 'dual_bound': s['dual_bound']}
+    nodes = s['evaluated_nodes']
+    pb = s['primal_bound']
     t.close()
+    if s['status'] == 4:
+        t = _ffi.Tree(p, ints, l, u, branch_rule='pseudo cost', max_batch=8192, pool_capacity=1 << pool_log2)
+        t.set_anchor_mode(True)
+        t.set_dive(max(1, dive))
+        if pb < inf:
+            t.set_primal_bound(pb)
+        while time.perf_counter() - t0 < limit:
+            s = t.solve(mip_gap=mip_gap, frontier_batch=8192, max_steps=10)
+            note(s, nodes)
+            if s['status'] != 4 or s['pool_exhausted']:
+                break
+        nodes += s['evaluated_nodes']
+        t.close()
+    el = time.perf_counter() - t0
     p.close()
+    return {'time_to_first_incumbent': first, 'phase_1_depth_first': phase1, 'status': _ffi.TREE_STATUS[s['status']],
+            'seconds': el, 'time_to_optimal': el if s['status'] == 1 else None,
+            'primal_bound': None if s['primal_bound'] == inf else s['primal_bound'], 'dual_bound': s['dual_bound'],
+            'gap': None if s['gap'] < 0 else s['gap'], 'nodes': nodes, 'pool_exhausted': bool(s['pool_exhausted']),
+            'time_to_gap': {f'{100 * mk:g}%': reached.get(mk) for mk in marks}}
+
+
+def time_to_optimal_leg(args, ctx, A, b, c, l, u, ints):
+    """The metric's second leg on its own 256 x 128 instance: the times at which the gap falls below
+    1 %, 0.5 %, 0.35 % ... inside the time limit (the tree of this instance does not close at 1e-4 at
+    any node rate reached so far: DESIGN.md section 5)."""
+    out = two_phase(ctx, A, b, c, l, u, ints, args.dive, dfs_seconds=0.5 * args.tto_seconds, limit=args.tto_seconds,
+                    pool_log2=23, marks=GAP_MARKS)
+    out.update({'instance': f'{len(c)} vars x {len(b)} rows, seed {args.seed} (the metric\'s own instance)',
+                'search': f'two phases in the native engine: depth first (1024 nodes per step) for {0.5 * args.tto_seconds:g} s, then '
+                          f'best first (8192 nodes per step) with the incumbent installed; in-place dive of depth {max(1, args.dive)}',
+                'time_limit_seconds': args.tto_seconds,
+                'note': 'time_to_optimal is null unless the gap closed to 1e-4 inside the time limit; time_to_gap: first time '
+                        'the gap (incumbent vs proven dual bound) was at or below the mark, null if never'})
     return out
 
 
-def small_time_to_optimal(ctx, dive):
-    """A SMALLER config than the metric's (80 x 40), kept for continuity with round 1: proven optimal."""
-    from simple_mip_solver_amd import _ffi
+def largest_closing_time_to_optimal(ctx, dive, n=128, m=64, limit=60.0):
+    """time_to_optimal on the LARGEST instance of the same generator that closes to mip_gap = 1e-4 inside
+    the stated limit (a smaller config than the metric's, labelled as such)."""
     from simple_mip_solver_amd.generators import random_dense_milp_arrays
-    A2, b2, c2, l2, u2, ints2 = random_dense_milp_arrays(80, 40, seed=0)
-    p2 = _ffi.Problem(ctx, A2, b2, c2)
-    best = None
-    for _ in range(3):  # a 25 ms solve: the fastest of three (allocation and first-touch effects)
-        t2 = _ffi.Tree(p2, ints2, l2, u2, branch_rule='pseudo cost', max_batch=4096, pool_capacity=1 << 21)
-        if dive:
-            t2.set_dive(True)
-        tt = time.perf_counter()
-        s2 = t2.solve(mip_gap=1e-4, frontier_batch=4096, max_seconds=30.0)
-        el2 = time.perf_counter() - tt
-        t2.close()
-        if best is None or el2 < best[0]:
-            best = (el2, s2)
-    p2.close()
-    el2, s2 = best
-    return {'instance': '80 vars x 40 rows, seed 0, same generator (a smaller config than the metric\'s)',
-            'seconds': el2, 'status': _ffi.TREE_STATUS[s2['status']], 'objective': s2['primal_bound'],
-            'nodes': s2['evaluated_nodes']}
+    A2, b2, c2, l2, u2, ints2 = random_dense_milp_arrays(n, m, seed=0)
+    out = two_phase(ctx, A2, b2, c2, l2, u2, ints2, dive, dfs_seconds=TTO_DFS_SECONDS, limit=limit, pool_log2=25)
+    out.update({'instance': f'{n} vars x {m} rows, seed 0, same generator (a SMALLER config than the metric\'s: the largest '
+                            f'that closes inside the limit)', 'time_limit_seconds': limit,
+                'search': f'two phases: depth first for {TTO_DFS_SECONDS:g} s, then best first with the incumbent installed'})
+    out.pop('time_to_gap', None)
+    return out
+
+
+TTO_DFS_SECONDS = 2.0
+
+
+def no_dive_leg(args, ctx, prob, l, u, ints, B):
+    """The same timed region WITHOUT the plunge (--dive 0): pure best first as north_star states it --
+    every LP of a step is one of the B best open nodes.  Same instance, ramp-up, re-anchoring and timing
+    brackets; fewer steps."""
+    from simple_mip_solver_amd import _ffi
+    steps = max(10, args.steps // 4)
+    n, m = prob.n, prob.m
+    pool = min(2 * B * (steps + 3 + 8) + 4 * B, int(40e9 // (2 * 8 * n + n + m)))
+    t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', search_rule='best first', strong_branch_iters=5,
+                  max_batch=B, pool_capacity=pool)
+    if not args.no_anchor:
+        t.set_anchor_mode(True)
+    st = t.stats()
+    while st['open_nodes'] < B or st['evaluated_nodes'] == 0:
+        st = t.solve(mip_gap=0.0, frontier_batch=min(B, 1024), max_steps=1)
+    if args.reanchor and not args.no_anchor:
+        t.reanchor(t.stats()['open_nodes'])
+    t.solve(mip_gap=0.0, frontier_batch=B, max_steps=3)
+    b0 = t.stats()
+    ctx.sync()
+    t0 = time.perf_counter()
+    st = t.solve(mip_gap=0.0, frontier_batch=B, max_steps=steps)
+    ctx.sync()
+    el = time.perf_counter() - t0
+    d = {k: st[k] - b0[k] for k in ('lp_solved', 'pivots', 'kernel_ms', 'steps', 'dives')}
+    t.close()
+    assert d['dives'] == 0 and d['steps'] == steps
+    return {'value': d['lp_solved'] / el, 'unit': 'node LP-relaxations/s', 'steps': steps, 'ms_per_step': el / steps * 1e3,
+            'launch_ms': d['kernel_ms'] / steps, 'lps_per_step': d['lp_solved'] / steps,
+            'mean_pivots_per_lp': d['pivots'] / max(1, d['lp_solved']),
+            'note': 'dive = 0: every LP of a step is one of the B best open nodes of the queue (pure best first)'}
 
 
 def other_configs(args, ctx):
@@ -489,23 +561,28 @@ def main():
         launch_s = d['kernel_ms'] * 1e-3 / max(1, d['steps'])
         model_gbps = algorithmic_bytes(m, n, d['lp_solved'], d['pivots'], d['dives']) / max(1, d['steps']) / launch_s / 1e9
         flops = 2.0 * m * n * d['pivots'] / max(1, d['steps']) / launch_s / 1e12
-        traffic, pmc_src, issue = None, None, None
+        traffic, pmc_src, issue, stale = None, None, None, None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
                 traffic, pmc_src, issue = pj.get('hbm_bytes_per_launch'), pj.get('command'), pj.get('issue')
+                # the counters were collected on the kernel sources with this hash: another hash now means the
+                # figure describes an older kernel -- it is reported as stale and no fraction is derived from it
+                stale = pj.get('csrc_sha256') != _ffi.source_hash()
             except Exception:
                 traffic = None
-        hbm_gbps = None if traffic is None else traffic / launch_s / 1e9
+        hbm_gbps = None if (traffic is None or stale) else traffic / launch_s / 1e9
+        nodive = no_dive_leg(args, ctx, prob, l, u, ints, B) if (world == 1 and args.dive and args.no_dive_leg) else None
         tto = time_to_optimal_leg(args, ctx, A, b, c, l, u, ints) if args.tto_seconds > 0 and (n, m) == (256, 128) else None
-        tto_small = small_time_to_optimal(ctx, args.dive) if args.tto_seconds > 0 else None
+        tto_small = largest_closing_time_to_optimal(ctx, args.dive) if args.tto_seconds > 0 else None
         highs = highs_baseline(args, prob, A, b, c, sample) if (sample is not None and args.highs_seconds > 0) else None
         others = other_configs(args, ctx) if args.others else None
         out = {
             'metric': 'node LP-relaxations/s', 'value': lps_total / elapsed_max,
             'unit': 'node LP-relaxations/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed_max / args.steps * 1e3,
+            'value_no_dive': None if nodive is None else nodive['value'], 'no_dive': nodive,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic' + (' (REHEARSAL: ranks share GPUs, gloo transport -- not a measurement)' if rehearsal else ''),
             'config': {
@@ -513,7 +590,9 @@ def main():
                             f'{args.seed}), PseudoCostBranchNode, best-first, strong_branch_iters=5, '
                             f'gomory_cuts=False, native frontier engine, {B} open nodes per step per GPU'
                             + (', every open node re-anchored after sharding' if args.reanchor and not args.no_anchor else '')
-                            + (f' + in-place dive (each node and, where the rule needs no probes, up to {args.dive} child(ren) in a row on the same register tableau)' if args.dive else ''),
+                            + (f' + in-place dive (each node and, where the rule needs no probes, up to {args.dive} child(ren) in a row on the same register tableau): '
+                               f'of the {d["lp_solved"] / max(1, d["steps"]):.0f} LPs of a step {d["dives"] / max(1, d["steps"]):.0f} are plunge children, '
+                               f'{(d["lp_solved"] - d["dives"]) / max(1, d["steps"]):.0f} are nodes popped from the best-first queue (value_no_dive: the same region without the plunge)' if args.dive else ''),
                 'frontier_batch_per_gpu': B, 'kernel': _ffi.kernel_name(m, n),
                 'anchored_refactorisation': not args.no_anchor, 'reanchored_after_sharding': bool(args.reanchor and not args.no_anchor), 'dive': args.dive,
                 'dive_children_per_step': d['dives'] / max(1, d['steps']),
@@ -525,7 +604,7 @@ def main():
                 'ramp_up_nodes': ramp['evaluated_nodes'],
                 'primal_bound': None if gp == float('inf') else gp, 'dual_bound': gd,
                 'gap': global_gap(gp, gd),
-                'time_to_optimal': tto, 'time_to_optimal_smaller_config': tto_small,
+                'time_to_optimal': tto, 'time_to_optimal_largest_closing_config': tto_small,
                 'exchanges': gstats['exchanges'], 'nodes_sent_rank0': gstats['nodes_sent'],
                 'nodes_received_rank0': gstats['nodes_received'],
                 'parallelism': f'open nodes sharded x{world}, per-GPU best-first queue; one all-gather per rank every '
@@ -539,7 +618,7 @@ def main():
                 # what the kernel really moves: PMC bytes (profiles/, same command) over the live launch time
                 'achieved': hbm_gbps, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                 'frac': None if hbm_gbps is None else hbm_gbps / HBM_PEAK_GBPS,
-                'traffic': traffic, 'traffic_source': pmc_src, 'launch_ms': launch_s * 1e3,
+                'traffic': traffic, 'traffic_stale': stale, 'traffic_source': pmc_src, 'launch_ms': launch_s * 1e3,
                 'model_hbm': {'achieved': model_gbps, 'frac': model_gbps / HBM_PEAK_GBPS, 'unit': 'GB/s',
                               'note': 'SURVEY 8d\'s dense-tableau HBM model (algorithmic bytes / launch time): the '
                                       'tableau is register-resident, this traffic does not happen -- not a roofline '

@@ -458,6 +458,11 @@ typedef struct mipx_exchange_decision {
 int mipx_exchange_record_len(int n);
 int mipx_exchange_decide(int world, int n, const double *records, double mip_gap, int allow_migration,
                          mipx_exchange_decision *out);
+/* Test hook: up to `amount` open nodes travel from this rank to itself through the communicator's
+ * point-to-point path (pack kernel -> ncclSend + ncclRecv to the own rank in one ncclGroupStart / End ->
+ * unpack kernel; custom transport: a device copy), i.e. what a migration does between two ranks.
+ * Returns the number of records moved.  Not with cut rounds, not with a step in flight. */
+int64_t mipx_tree_migrate_self(mipx_tree *t, int64_t amount);
 /* Test hook: the record this rank would post right now (mipx_exchange_record_len(n) doubles; callable
  * from a step hook, i.e. with steps in flight). */
 int mipx_tree_exchange_record(mipx_tree *t, double *record);

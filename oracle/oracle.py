@@ -214,10 +214,16 @@ def gomory(A, b, c, l, u, vstat, x, int_idx, max_term=1e3):
 
     Returns dict(row_idx, pi, pi0, safe_pi, safe_pi0) with one row per cut.
     """
+    _, dump = debug_dump(A, b, c, l, u, vstat, 0)
+    return gomory_from_dump(A, b, dump, x, int_idx, max_term)
+
+
+def gomory_from_dump(A, b, dump, x, int_idx, max_term=1e3):
+    """The same from a tableau state a solve ended with (debug_dump): what the engine's batched cut rounds
+    read (the LP launch dumps the tableau it ends with; no launch of its own refactors one)."""
     A = np.ascontiguousarray(A, np.float64)
     m, n = A.shape
     b = np.ascontiguousarray(b, np.float64)
-    _, dump = debug_dump(A, b, c, l, u, vstat, 0)
     T = np.ascontiguousarray(dump['T']); bvar = np.ascontiguousarray(dump['bvar'], np.int32)
     nvar = np.ascontiguousarray(dump['nvar'], np.int32)
     is_int = np.zeros(n, np.uint8); is_int[np.asarray(int_idx, int)] = 1

@@ -2,7 +2,7 @@
 import collections, csv, glob, json, os, sys
 O = sys.argv[1]
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = os.environ.get('PROFILE_TAG', 'r02')
+TAG = os.environ.get('PROFILE_TAG', 'r03')
 
 
 def newest(pattern):
@@ -59,7 +59,10 @@ if issue.get('SQ_WAVE_CYCLES'):
         'wait_any_over_wave_cycles': issue.get('SQ_WAIT_ANY', 0) / wc,
         'note': 'per launch of the steady-state node-LP kernel; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count '
                 'quad-cycles summed over waves (MI355X_MICROARCH.md), SQ_INSTS_* count wave-instructions'}
-out = {"command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ groups (separate passes) -- python3 bench.py " + args,
+sys.path.insert(0, R)
+from simple_mip_solver_amd._ffi import source_hash
+out = {"csrc_sha256": source_hash(),
+       "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ groups (separate passes) -- python3 bench.py " + args,
        "kernel": f"lp_dual_simplex (K1), grid {g} threads per launch (one frontier batch)",
        "fetch_size_KB_raw": f_kb, "write_size_KB": w_kb,
        "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM)",

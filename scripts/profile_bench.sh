@@ -8,11 +8,11 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/prof
 rm -rf $O && mkdir -p $O
-ARGS="--steps ${STEPS:-10} --warmup 3 --cpu-seconds 0 --highs-seconds 0 --tto-seconds 0 --others 0 ${EXTRA:-}"
+ARGS="--steps ${STEPS:-10} --warmup 3 --cpu-seconds 0 --highs-seconds 0 --tto-seconds 0 --others 0 --no-dive-leg 0 ${EXTRA:-}"
 echo "$ARGS" > $O/args.txt
 # the kernel trace over the bench's own default timed region (200 steps), so that its average launch time
 # is the figure the default bench.py run measures live; the counter passes take fewer steps
-TARGS="--cpu-seconds 0 --highs-seconds 0 --tto-seconds 0 --others 0 ${EXTRA:-}"
+TARGS="--cpu-seconds 0 --highs-seconds 0 --tto-seconds 0 --others 0 --no-dive-leg 0 ${EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py $TARGS > $O/trace.log 2>&1
 echo trace done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py $ARGS > $O/fetch.log 2>&1

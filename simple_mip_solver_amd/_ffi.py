@@ -25,7 +25,7 @@ SYMBOLS = [
     'mipx_comm_destroy', 'mipx_comm_rank', 'mipx_comm_size', 'mipx_comm_allgather', 'mipx_comm_barrier',
     'mipx_tree_set_comm', 'mipx_tree_global_stats', 'mipx_exchange_record_len', 'mipx_exchange_decide',
     'mipx_tree_exchange_record', 'mipx_tree_trace_cuts', 'mipx_tree_peek_cuts', 'mipx_tree_cut_store',
-    'mipx_tree_cut_rows_per_node',
+    'mipx_tree_cut_rows_per_node', 'mipx_tree_migrate_self',
     'mipx_dev_alloc', 'mipx_dev_free',
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
@@ -88,6 +88,20 @@ class ExchangeDecision(C.Structure):
     _fields_ = [('primal', C.c_double), ('dual', C.c_double), ('gap', C.c_double), ('sums', C.c_int64 * 4),
                 ('open_nodes', C.c_int64), ('incumbent_rank', C.c_int32), ('done', C.c_int32),
                 ('reason', C.c_int32), ('n_moves', C.c_int32), ('moves', C.c_int32 * 192)]
+
+
+def source_hash():
+    """sha256 over the kernel / engine sources next to libmipx.so (csrc/*.hip, *.h, in name order).  The
+    profiling scripts store it beside the counters they collect; bench.py flags a counter-based roofline
+    figure as stale when the sources have changed since (profiles/pmc_latest.json)."""
+    import hashlib
+    d = os.path.dirname(LIB_PATH)
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()
 
 
 def exchange_record_len(n):
@@ -692,6 +706,17 @@ class Tree:
         self._comm = comm
         self.problem.ctx.check(L.mipx_tree_set_comm(self._h, None if comm is None else comm._h, int(every_steps)),
                                'mipx_tree_set_comm')
+
+    def migrate_self(self, amount):
+        """Test hook (mipx_tree_migrate_self): up to `amount` open nodes leave and re-enter this rank through
+        the communicator's point-to-point path; returns how many moved."""
+        L = lib()
+        L.mipx_tree_migrate_self.argtypes = [_vp, C.c_int64]
+        L.mipx_tree_migrate_self.restype = C.c_int64
+        k = L.mipx_tree_migrate_self(self._h, int(amount))
+        if k < 0:
+            self.problem.ctx.check(int(k), 'mipx_tree_migrate_self')
+        return int(k)
 
     def exchange_record(self):
         """The record this rank would post right now (mipx_tree_exchange_record; needs set_comm)."""

@@ -23,6 +23,8 @@ struct RcclApi {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -65,8 +67,11 @@ int rccl_load(mipx_ctx *ctx) {
     a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
     a.Send = (decltype(a.Send))dlsym(h, "ncclSend");
     a.Recv = (decltype(a.Recv))dlsym(h, "ncclRecv");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.Send || !a.Recv)
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.Send || !a.Recv || !a.GroupStart ||
+        !a.GroupEnd)
         return fail(ctx, MIPX_ENODEV, "mipx_comm: librccl.so lacks a needed entry point");
     g_rccl = a;
     return MIPX_OK;
@@ -171,6 +176,26 @@ int comm_recv_dev(mipx_comm *c, int peer, void *dev, size_t bytes) {
     c->c_send.resize(bytes);
     if (c->ops.recv(c->user, peer, c->c_send.data(), bytes) != 0) return fail(ctx, MIPX_EHIP, "mipx_comm: the custom recv failed");
     HIP_TRY(ctx, hipMemcpy(dev, c->c_send.data(), bytes, hipMemcpyHostToDevice));
+    return MIPX_OK;
+}
+
+// A block goes from this rank to itself through the point-to-point path (the send and the matching
+// receive fused in one group, as RCCL requires of a rank that talks to itself): what a migration does
+// between two ranks, on one.  Custom transport: a device-to-device copy.
+int comm_sendrecv_self(mipx_comm *c, const void *src, void *dst, size_t bytes) {
+    mipx_ctx *ctx = c->ctx;
+    if (c->rccl) {
+        RCCL_TRY(ctx, g_rccl.GroupStart());
+        const ncclResult_t rs = g_rccl.Send(src, bytes, ncclChar, c->rank, c->nccl, c->stream);
+        const ncclResult_t rr = rs == ncclSuccess ? g_rccl.Recv(dst, bytes, ncclChar, c->rank, c->nccl, c->stream) : rs;
+        const ncclResult_t re = g_rccl.GroupEnd();
+        if (rs != ncclSuccess) return rccl_fail(ctx, "ncclSend (to self)", rs);
+        if (rr != ncclSuccess) return rccl_fail(ctx, "ncclRecv (from self)", rr);
+        if (re != ncclSuccess) return rccl_fail(ctx, "ncclGroupEnd", re);
+        HIP_TRY(ctx, hipStreamSynchronize(c->stream));
+        return MIPX_OK;
+    }
+    HIP_TRY(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
     return MIPX_OK;
 }
 

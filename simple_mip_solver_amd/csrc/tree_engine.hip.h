@@ -1194,91 +1194,125 @@ void x_fill_record(mipx_tree *t) {
 // every rank).  The donor gives every second of its best 2 * amount open nodes, so that both keep
 // good ones; fewer if it has consumed them since it posted (the message has the planned size, a
 // count in front says how many records are real).
-int x_migrate(mipx_tree *t, int from, int to, int64_t amount) {
-    mipx_comm *c = t->comm;
-    mipx_ctx *ctx = t->ctx;
-    const int me = c->rank;
-    if (me != from && me != to) return MIPX_OK;
+struct MigLayout { size_t rowbytes, meta_off, bytes; };
+MigLayout mig_layout(const mipx_tree *t, int64_t amount) {
     const size_t n = (size_t)t->n, nvs = n + (size_t)t->mrows;
-    const size_t rowbytes = 16 * n + (nvs + 7) / 8 * 8;
-    const size_t meta_off = (size_t)amount * rowbytes, bytes = meta_off + (1 + 5 * (size_t)amount) * 8;
-    char *msg = nullptr;
-    int rc = comm_msg_buffer(c, bytes + (size_t)amount * 4, &msg);   // (+ the slot list of the pack kernels)
-    if (rc) return rc;
-    int32_t *d_slots = (int32_t *)(msg + bytes);
+    MigLayout L;
+    L.rowbytes = 16 * n + (nvs + 7) / 8 * 8;
+    L.meta_off = (size_t)amount * L.rowbytes;
+    L.bytes = L.meta_off + (1 + 5 * (size_t)amount) * 8;
+    return L;
+}
+mipx::PackArgs mig_args(mipx_tree *t, const MigLayout &L, char *msg, int32_t *d_slots) {
+    mipx::PackArgs pa;
+    pa.n = t->n; pa.nvs = t->n + t->mrows; pa.rowbytes = L.rowbytes; pa.slot = d_slots;
+    pa.pool_l = t->pool_l; pa.pool_u = t->pool_u; pa.pool_v = t->pool_v; pa.msg = msg;
+    pa.count = 0;
+    return pa;
+}
+
+// donor half: up to `amount` records leave the queue and are packed into msg (device memory)
+int mig_pack(mipx_tree *t, const MigLayout &L, char *msg, int32_t *d_slots, int64_t amount, std::vector<int32_t> &slots,
+             int64_t *count) {
+    mipx_ctx *ctx = t->ctx;
+    std::vector<double> meta(1 + 5 * (size_t)amount, 0.0);
+    mipx::PackArgs pa = mig_args(t, L, msg, d_slots);
+    // the child records of the last finished step may still be in the making on st3: the donor must not
+    // pack rows before they are written
+    if (t->child_recorded) HIP_TRY(ctx, hipStreamWaitEvent(t->st2, t->ev_child, 0));
+    const int64_t have = tree_open_count(t);
+    const int64_t give = std::max<int64_t>(0, std::min<int64_t>(amount, (have - t->x_batch) / 2));
+    std::vector<int64_t> ids;
+    if (t->use_bq) {
+        t->popped.clear();
+        t->bq.pop_batch((size_t)(2 * give), t->popped);
+        for (const auto &it : t->popped) ids.push_back(it.id);
+    } else {
+        for (int64_t k = 0; k < 2 * give && !t->heap.empty(); k++) ids.push_back(t->heap.pop());
+    }
+    int64_t cnt = 0;
+    for (size_t k = 0; k < ids.size(); k++) {
+        NodeRec &nd = t->nodes[ids[k]];
+        if (t->search != 0) t->is_open[ids[k]] = 0;
+        if ((k & 1) == 0 || cnt >= give) { tree_push(t, ids[k]); continue; }   // kept
+        double *mrec = meta.data() + 1 + 5 * cnt;
+        mrec[0] = nd.dual_bound; mrec[1] = nd.b_val; mrec[2] = (double)nd.depth;
+        mrec[3] = (double)nd.b_idx; mrec[4] = (double)nd.b_dir;
+        slots.push_back(nd.slot);
+        nd.slot = -1;
+        cnt++;
+    }
+    meta[0] = (double)cnt;
+    if (cnt > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_slots, slots.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, t->st2));
+        pa.count = (int)cnt;
+        hipLaunchKernelGGL(mipx::pack_nodes, dim3((unsigned)cnt), dim3(256), 0, t->st2, pa);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(msg + L.meta_off, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, t->st2));
+    HIP_TRY(ctx, hipStreamSynchronize(t->st2));
+    *count = cnt;
+    return MIPX_OK;
+}
+
+// receiver half: the records of msg (device memory) get pool rows and join the queue
+int mig_unpack(mipx_tree *t, const MigLayout &L, char *msg, int32_t *d_slots, int64_t amount, int64_t *count) {
+    mipx_ctx *ctx = t->ctx;
     std::vector<double> meta(1 + 5 * (size_t)amount, 0.0);
     std::vector<int32_t> slots;
-    mipx::PackArgs pa;
-    pa.n = (int)n; pa.nvs = (int)nvs; pa.rowbytes = rowbytes; pa.slot = d_slots;
-    pa.pool_l = t->pool_l; pa.pool_u = t->pool_u; pa.pool_v = t->pool_v; pa.msg = msg;
-    // the child records of the last finished step may still be in the making on st3: the donor must not
-    // pack rows before they are written, the receiver must not overwrite the parents' rows (free again
-    // on the host) before they have been read
+    mipx::PackArgs pa = mig_args(t, L, msg, d_slots);
+    HIP_TRY(ctx, hipMemcpy(meta.data(), msg + L.meta_off, meta.size() * 8, hipMemcpyDeviceToHost));
+    const int64_t cnt = (int64_t)meta[0];
+    if (cnt < 0 || cnt > amount) return fail(ctx, MIPX_EHIP, "tree: corrupt migration message");
+    // (the amount was capped by the room this rank reported in its record -- x_decide -- which left the
+    // claims of the steps in flight aside; batch_size() keeps later steps within what is left)
+    if ((int64_t)t->free_slots.size() < cnt)
+        return fail(ctx, MIPX_ENOMEM, "tree: node pool too small for the migrated nodes (raise pool_capacity)");
+    // the parents' rows freed by the last finished step may still be read by its make_children on st3
     if (t->child_recorded) HIP_TRY(ctx, hipStreamWaitEvent(t->st2, t->ev_child, 0));
-    if (me == from) {
-        const int64_t have = tree_open_count(t);
-        const int64_t give = std::max<int64_t>(0, std::min<int64_t>(amount, (have - t->x_batch) / 2));
-        std::vector<int64_t> ids;
-        if (t->use_bq) {
-            t->popped.clear();
-            t->bq.pop_batch((size_t)(2 * give), t->popped);
-            for (const auto &it : t->popped) ids.push_back(it.id);
-        } else {
-            for (int64_t k = 0; k < 2 * give && !t->heap.empty(); k++) ids.push_back(t->heap.pop());
-        }
-        int64_t cnt = 0;
-        for (size_t k = 0; k < ids.size(); k++) {
-            NodeRec &nd = t->nodes[ids[k]];
-            if (t->search != 0) t->is_open[ids[k]] = 0;
-            if ((k & 1) == 0 || cnt >= give) { tree_push(t, ids[k]); continue; }   // kept
-            double *mrec = meta.data() + 1 + 5 * cnt;
-            mrec[0] = nd.dual_bound; mrec[1] = nd.b_val; mrec[2] = (double)nd.depth;
-            mrec[3] = (double)nd.b_idx; mrec[4] = (double)nd.b_dir;
-            slots.push_back(nd.slot);
-            nd.slot = -1;
-            cnt++;
-        }
-        meta[0] = (double)cnt;
-        if (cnt > 0) {
-            HIP_TRY(ctx, hipMemcpyAsync(d_slots, slots.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, t->st2));
-            pa.count = (int)cnt;
-            hipLaunchKernelGGL(mipx::pack_nodes, dim3((unsigned)cnt), dim3(256), 0, t->st2, pa);
-            HIP_TRY(ctx, hipGetLastError());
-        }
-        HIP_TRY(ctx, hipMemcpyAsync(msg + meta_off, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, t->st2));
+    for (int64_t k = 0; k < cnt; k++) {
+        const double *mrec = meta.data() + 1 + 5 * k;
+        NodeRec nd;
+        nd.dual_bound = mrec[0]; nd.b_val = mrec[1]; nd.depth = (int32_t)mrec[2];
+        nd.b_idx = (int32_t)mrec[3]; nd.b_dir = (int32_t)mrec[4];
+        nd.key = t->search == 0 ? nd.dual_bound : -(double)nd.depth;
+        nd.anchor = -1; nd.born = (int32_t)t->steps; nd.ncut = 0;
+        nd.slot = t->free_slots.back();
+        t->free_slots.pop_back();
+        slots.push_back(nd.slot);
+        t->nodes.push_back(nd);
+        tree_push(t, (int64_t)t->nodes.size() - 1);
+    }
+    if (cnt > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_slots, slots.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, t->st2));
+        pa.count = (int)cnt;
+        hipLaunchKernelGGL(mipx::unpack_nodes, dim3((unsigned)cnt), dim3(256), 0, t->st2, pa);
+        HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipStreamSynchronize(t->st2));
-        if ((rc = comm_send_dev(c, to, msg, bytes))) return rc;
+    }
+    *count = cnt;
+    return MIPX_OK;
+}
+
+int x_migrate(mipx_tree *t, int from, int to, int64_t amount) {
+    mipx_comm *c = t->comm;
+    const int me = c->rank;
+    if (me != from && me != to) return MIPX_OK;
+    const MigLayout L = mig_layout(t, amount);
+    char *msg = nullptr;
+    int rc = comm_msg_buffer(c, L.bytes + (size_t)amount * 4, &msg);   // (+ the slot list of the pack kernels)
+    if (rc) return rc;
+    int32_t *d_slots = (int32_t *)(msg + L.bytes);
+    int64_t cnt = 0;
+    if (me == from) {
+        std::vector<int32_t> slots;
+        if ((rc = mig_pack(t, L, msg, d_slots, amount, slots, &cnt))) return rc;
+        if ((rc = comm_send_dev(c, to, msg, L.bytes))) return rc;
         for (int32_t sl : slots) t->free_slots.push_back(sl);
         t->nodes_sent += cnt;
     } else {
-        if ((rc = comm_recv_dev(c, from, msg, bytes))) return rc;
-        HIP_TRY(ctx, hipMemcpy(meta.data(), msg + meta_off, meta.size() * 8, hipMemcpyDeviceToHost));
-        const int64_t cnt = (int64_t)meta[0];
-        if (cnt < 0 || cnt > amount) return fail(ctx, MIPX_EHIP, "tree: corrupt migration message");
-        // (the amount was capped by the room this rank reported in its record -- x_decide -- which left the
-        // claims of the steps in flight aside; batch_size() keeps later steps within what is left)
-        if ((int64_t)t->free_slots.size() < cnt)
-            return fail(ctx, MIPX_ENOMEM, "tree: node pool too small for the migrated nodes (raise pool_capacity)");
-        for (int64_t k = 0; k < cnt; k++) {
-            const double *mrec = meta.data() + 1 + 5 * k;
-            NodeRec nd;
-            nd.dual_bound = mrec[0]; nd.b_val = mrec[1]; nd.depth = (int32_t)mrec[2];
-            nd.b_idx = (int32_t)mrec[3]; nd.b_dir = (int32_t)mrec[4];
-            nd.key = t->search == 0 ? nd.dual_bound : -(double)nd.depth;
-            nd.anchor = -1; nd.born = (int32_t)t->steps; nd.ncut = 0;
-            nd.slot = t->free_slots.back();
-            t->free_slots.pop_back();
-            slots.push_back(nd.slot);
-            t->nodes.push_back(nd);
-            tree_push(t, (int64_t)t->nodes.size() - 1);
-        }
-        if (cnt > 0) {
-            HIP_TRY(ctx, hipMemcpyAsync(d_slots, slots.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, t->st2));
-            pa.count = (int)cnt;
-            hipLaunchKernelGGL(mipx::unpack_nodes, dim3((unsigned)cnt), dim3(256), 0, t->st2, pa);
-            HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipStreamSynchronize(t->st2));
-        }
+        if ((rc = comm_recv_dev(c, from, msg, L.bytes))) return rc;
+        if ((rc = mig_unpack(t, L, msg, d_slots, amount, &cnt))) return rc;
         t->nodes_received += cnt;
     }
     return MIPX_OK;
@@ -2018,6 +2052,42 @@ int mipx_tree_set_comm(mipx_tree *t, mipx_comm *c, int every_steps) {
     t->x_rounds = 0;
     t->x_done = false;
     return MIPX_OK;
+}
+
+/* Test hook: a donation of up to `amount` open nodes from this rank to ITSELF through the communicator's
+ * point-to-point path -- pack kernel, ncclSend + ncclRecv to the own rank inside one ncclGroupStart /
+ * ncclGroupEnd (custom transport: a device copy), unpack kernel -- so that the wrappers of a migration
+ * run on RCCL on a one-GPU box.  The nodes come back under new ids in fresh pool rows; the search is
+ * otherwise unchanged.  Returns the number of records moved (>= 0) or an error. */
+int64_t mipx_tree_migrate_self(mipx_tree *t, int64_t amount) {
+    if (!t || amount < 1) return MIPX_EINVAL;
+    if (!t->comm) return fail(t->ctx, MIPX_EINVAL, "mipx_tree_migrate_self: no communicator attached");
+    if (t->cuts) return fail(t->ctx, MIPX_EINVAL, "mipx_tree_migrate_self: not with cut rounds");
+    for (const StepBuf &S : t->buf)
+        if (S.in_flight) return fail(t->ctx, MIPX_EINVAL, "mipx_tree_migrate_self: a step is in flight");
+    mipx_comm *c = t->comm;
+    mipx_ctx *ctx = t->ctx;
+    if (amount > kMaxMigrate) amount = kMaxMigrate;
+    const MigLayout L = mig_layout(t, amount);
+    const size_t half = (L.bytes + 255) / 256 * 256;
+    char *msg = nullptr;
+    int rc = comm_msg_buffer(c, 2 * half + (size_t)amount * 4, &msg);
+    if (rc) return rc;
+    int32_t *d_slots = (int32_t *)(msg + 2 * half);
+    std::vector<int32_t> slots;
+    int64_t sent = 0, got = 0;
+    const int keep_batch = t->x_batch;
+    t->x_batch = 0;   // (a test may move every open node)
+    rc = mig_pack(t, L, msg, d_slots, amount, slots, &sent);
+    t->x_batch = keep_batch;
+    if (rc) return rc;
+    if ((rc = comm_sendrecv_self(c, msg, msg + half, L.bytes))) return rc;
+    for (int32_t sl : slots) t->free_slots.push_back(sl);
+    if ((rc = mig_unpack(t, L, msg + half, d_slots, amount, &got))) return rc;
+    if (got != sent) return fail(ctx, MIPX_EHIP, "mipx_tree_migrate_self: the count did not survive the round trip");
+    t->nodes_sent += sent;
+    t->nodes_received += got;
+    return got;
 }
 
 int mipx_tree_global_stats(mipx_tree *t, mipx_tree_global_stats_t *out) {

@@ -338,15 +338,22 @@ def test_cut_mode_limits():
 
 
 # ---- (4) one step of the BATCHED cut mode, node by node through the oracle ---------------------------
-def replay_cut_loop(oracle, A, b, c, l, u, ints, first, rows_pi, rows_pi0, vstat, params):
+def replay_cut_loop(oracle, A, b, c, l, u, ints, first, rows_pi, rows_pi0, vstat, params, first_dump=None,
+                    root_anchor=None):
     """BaseNode._base_bound's loop (base_node.py:196-203, :292-341) for one node on oracle pieces only:
     `first` is the node's LP result, rows_pi / rows_pi0 the cut rows it carries, vstat its basis over
-    n + m + cuts.  Returns (8 counters like mipx_tree_trace_cuts, status, objective)."""
+    n + m + cuts.  first_dump = None: every round's tableau is refactored from the basis (the per-node
+    path, exact_tableau = 1).  first_dump given (the tableau state the first solve ended with): the
+    batched mode -- a round reads the tableau the last solve ENDED WITH, and a tableau of its own only
+    where it starts by removing rows (from the root's tableau if no cut row is left and the root has
+    one, else from the slack basis).  Returns (8 counters like mipx_tree_trace_cuts, status, objective)."""
+    import contextlib
     m, n = A.shape
     rows_pi, rows_pi0 = [np.asarray(p) for p in rows_pi], list(rows_pi0)
     cnt = dict(rounds=0, it_created=0, n_created=0, it_added=0, n_added=0, it_removed=0, n_removed=0)
     pool_pi, pool_pi0 = [], []
-    r, stalled = first, False
+    r, dump, stalled = first, first_dump, False
+    fused = first_dump is not None
     vstat = np.asarray(vstat, np.int8).copy()
 
     def materialised():
@@ -370,9 +377,15 @@ def replay_cut_loop(oracle, A, b, c, l, u, ints, first, rows_pi, rows_pi0, vstat
                 vstat = np.concatenate([vstat[:n + m], vstat[n + m:][keep]])
                 rows_pi = [rows_pi[k] for k in keep]; rows_pi0 = [rows_pi0[k] for k in keep]
                 changed = True
+                if fused:   # the dumped tableau has the removed rows in it: one of its own
+                    Ak, bk = materialised()
+                    cm = oracle.anchored(root_anchor) if (root_anchor is not None and not rows_pi) else contextlib.nullcontext()
+                    with cm:
+                        _, dump = oracle.debug_dump(Ak, bk, c, l, u, vstat, 0)
         Ak, bk = materialised()
         x = np.maximum(r['x'], 0)
-        g = oracle.gomory(Ak, bk, c, l, u, vstat, x, ints, params['max_term'])
+        g = oracle.gomory_from_dump(Ak, bk, dump, x, ints, params['max_term']) if fused else \
+            oracle.gomory(Ak, bk, c, l, u, vstat, x, ints, params['max_term'])
         if len(g['row_idx']):
             cnt['it_created'] += 1; cnt['n_created'] += len(g['row_idx'])
         pool_pi += list(g['safe_pi']); pool_pi0 += list(g['safe_pi0'])
@@ -389,7 +402,11 @@ def replay_cut_loop(oracle, A, b, c, l, u, ints, first, rows_pi, rows_pi0, vstat
             changed = True
         if changed:     # (an unchanged LP is not re-solved by the engine: same objective, it stalls either way)
             Ak, bk = materialised()
-            r = oracle.lp_solve(Ak, bk, c, l, u, vstat)
+            if fused:
+                rb, dump = oracle.debug_dump(Ak, bk, c, l, u, vstat, 0)
+                r = {k: v[0] for k, v in rb.items()}
+            else:
+                r = oracle.lp_solve(Ak, bk, c, l, u, vstat)
             vstat = r['vstat']
         new = r['obj'] if r['status'] in (0, 2) else INF
         with np.errstate(invalid='ignore', divide='ignore'):
@@ -399,17 +416,19 @@ def replay_cut_loop(oracle, A, b, c, l, u, ints, first, rows_pi, rows_pi0, vstat
              cnt['n_removed'], len(rows_pi)], r['status'], r['obj'] if r['status'] in (0, 2) else INF)
 
 
+@pytest.mark.parametrize('exact', [0, 1])
 @pytest.mark.parametrize('n,m,seed,density,boxed,target,MB', [
     (256, 128, 0, 1.0, True, 400, 1024),     # BASELINE C4: the bench's family (cuts created, none added)
-    (256, 128, 1, 1.0, False, 200, 512),     # 256 x 128 where the reference's rules DO add cuts
+    (256, 128, 1, 1.0, False, 200, 512),     # 256 x 128 where the reference's rules DO add cuts: nodes carry rows
     (64, 32, 5, 1.0, False, 200, 512),       # nodes that carry, gain and lose cut rows
     (64, 32, 2, 0.25, True, 200, 512)])
-def test_batched_cut_mode_step_replays_through_the_oracle(n, m, seed, density, boxed, target, MB, gpu_ctx, oracle):
+def test_batched_cut_mode_step_replays_through_the_oracle(n, m, seed, density, boxed, target, MB, exact, gpu_ctx, oracle):
     """The configuration bench.py measures C4 on -- exact_tableau=0 (K2 reads the tableau a solve ends
     with), anchored, re-anchored, a whole frontier per step -- checked at step level: every node of one
     step against the oracle's replay of BaseNode._base_bound on the same record (bounds, basis, the cut
     rows it carries): cut rounds, GMICs created / added / removed, cut rows kept, final LP status, final
-    objective to 1e-9."""
+    objective to 1e-9.  exact = 1: the same batch with the per-node path's tableau (refactored per round)."""
+    import contextlib
     import math
     A, b, c, l, u, ints = random_dense_milp_arrays(n, m, density=density, seed=seed)
     if not boxed:
@@ -418,7 +437,7 @@ def test_batched_cut_mode_step_replays_through_the_oracle(n, m, seed, density, b
     params = dict(max_rounds=10, progress_tol=1e-4, min_cut_depth=1e-8, cos_parallel=math.cos(math.radians(10)),
                   max_abs_coef=1000.0 * float(np.max(np.abs(A))), max_term=1e3)
     t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=MB, pool_capacity=1 << 15,
-                  cut_params=dict(max_abs_coef=params['max_abs_coef'], exact_tableau=0))
+                  cut_params=dict(max_abs_coef=params['max_abs_coef'], exact_tableau=exact))
     t.set_anchor_mode(True)
     st = t.stats()
     while st['open_nodes'] < target:
@@ -438,25 +457,11 @@ def test_batched_cut_mode_step_replays_through_the_oracle(n, m, seed, density, b
     tr, tc = t.trace(), t.trace_cuts()
     assert len(tr['node_id']) == len(tc) > 0 and set(tr['node_id']) <= set(ids.tolist())
     where = {int(i): k for k, i in enumerate(ids)}
-    # first LPs of the nodes without cut rows: from the anchor their record names (own table entry, else
-    # the root's tableau -- which exists only if the root kept no cut row)
+    # the root's tableau is an anchor only if the root kept no cut row (its final basis is then its LP optimum's:
+    # rounds that add no row leave the basis alone)
     root = oracle.lp_solve(A, b, c, l, u)
-    root_kept_rows = store_pi0.size > 0 and replay_cut_loop(oracle, A, b, c, l, u, ints, root, [], [], root['vstat'],
-                                                            params)[0][7] > 0
-    plain = [where[int(i)] for i in tr['node_id'] if ncut[where[int(i)]] == 0]
-    zero = np.zeros(n)
-    import contextlib
-    cm = contextlib.nullcontext()
-    if not root_kept_rows:
-        # (the root's final basis: its LP optimum -- rounds that add no row leave it alone)
-        cm = oracle.anchored(oracle.make_anchor(A, b, c, root['vstat']))
-    with cm:
-        fo = oracle.lp_solve_dive_batch(A, b, c, L[plain], U[plain], V[plain], -1, ints, zero, zero,
-                                        np.zeros(n, np.uint8), INF, anchor_table=atab,
-                                        anchor_sel=None if atab is None else sel[plain]) if plain else None
-    first = {}
-    for j, k in enumerate(plain):
-        first[k] = dict(status=int(fo['status'][j]), obj=float(fo['obj'][j]), x=fo['x'][j], vstat=fo['vstat'][j])
+    root_kept_rows = replay_cut_loop(oracle, A, b, c, l, u, ints, root, [], [], root['vstat'], params)[0][7] > 0
+    root_anchor = None if root_kept_rows else oracle.make_anchor(A, b, c, root['vstat'])
     seen_rows = seen_added = seen_removed = 0
     for pos, nid in enumerate(tr['node_id']):
         k = where[int(nid)]
@@ -464,21 +469,27 @@ def test_batched_cut_mode_step_replays_through_the_oracle(n, m, seed, density, b
         rp0 = [store_pi0[i] for i in lists[k, :ncut[k]]]
         vfull = np.concatenate([V[k], codes[k, :ncut[k]]])
         if ncut[k] == 0:
-            f = first[k]
-        else:
-            Ak = np.vstack([A] + [p[None] for p in rp]); bk = np.concatenate([b, rp0])
-            f = oracle.lp_solve(Ak, bk, c, L[k], U[k], vfull)
-            vfull = f['vstat'] if f['status'] in (0, 2) else vfull
-        if ncut[k] == 0 and f['status'] in (0, 2):
+            # the first LP refactors from the anchor the record names: its own table entry, else the root's
+            # tableau, else the slack basis
+            anchor = root_anchor if sel[k] < 0 else dict(T=atab[0][sel[k]], vec=atab[1][sel[k]], idx=atab[2][sel[k]])
+            with (oracle.anchored(anchor) if anchor is not None else contextlib.nullcontext()):
+                fb, dump = oracle.debug_dump(A, b, c, L[k], U[k], vfull, 0)
+        else:       # a node that carries cut rows refactors from the slack basis of its own rows
+            fb, dump = oracle.debug_dump(np.vstack([A] + [p[None] for p in rp]), np.concatenate([b, rp0]), c, L[k], U[k], vfull, 0)
+        f = {key: v[0] for key, v in fb.items()}
+        if f['status'] in (0, 2):
             vfull = f['vstat']
-        counters, status, obj = replay_cut_loop(oracle, A, b, c, L[k], U[k], ints, f, rp, rp0, vfull, params)
+        counters, status, obj = replay_cut_loop(oracle, A, b, c, L[k], U[k], ints, f, rp, rp0, vfull, params,
+                                                first_dump=None if exact else dump, root_anchor=root_anchor)
         assert tr['status'][pos] == status, (pos, int(nid), tr['status'][pos], status)
-        assert tc[pos].tolist() == counters, (pos, int(nid), tc[pos].tolist(), counters)
+        assert tc[pos].tolist() == counters, (pos, int(nid), ncut[k], tc[pos].tolist(), counters)
         if status in (0, 2):
             assert isclose(tr['objective'][pos], obj, rel_tol=1e-9, abs_tol=1e-9), (pos, tr['objective'][pos], obj)
         seen_rows += ncut[k] > 0; seen_added += counters[4]; seen_removed += counters[6]
     assert tc[:, 2].sum() > 0                      # GMICs were created
-    if (n, boxed) != (256, True):                  # ... and on these shapes added, carried and dropped again
-        assert seen_added > 0 and seen_rows > 0
+    if (n, boxed) != (256, True):                  # ... and on these shapes nodes carry cut rows into the step
+        assert seen_rows > 0
+    if (n, m, seed) == (64, 32, 5):                # ... gain and lose them
+        assert seen_added > 0 and seen_removed > 0
     t.close()
     prob.close()

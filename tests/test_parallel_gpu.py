@@ -81,6 +81,57 @@ def test_rccl_one_rank_collective_solve():
     assert abs(float(c @ x) - st['primal_bound']) < 1e-6 and abs(float(c @ xr) - ref['primal_bound']) < 1e-6
 
 
+@pytest.mark.parametrize('transport', ['rccl', 'custom'])
+def test_point_to_point_path_to_self(transport):
+    """The wrappers a migration goes through -- pack_nodes, ncclSend + ncclRecv (one group), unpack_nodes --
+    on RCCL with the one rank a one-GPU box allows: open nodes leave the queue, travel to the own rank and
+    re-enter under new ids in fresh pool rows.  The records arrive intact (bounds, bases, inherited bounds)
+    and the search ends exactly like the one that moved nothing."""
+    from simple_mip_solver_amd import _ffi
+    from simple_mip_solver_amd.generators import random_dense_milp_arrays
+    ctx = _ffi.default_context()
+    if transport == 'rccl':
+        comm = _ffi.Comm(ctx, 0, 1, unique_id=_ffi.comm_unique_id())
+    else:
+        comm = _ffi.Comm(ctx, 0, 1, allgather=lambda b: [b], send=lambda p, d: None, recv=lambda p, k: b'')
+    assert comm.transport == transport
+    n, m, B = 40, 16, 16
+    A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=3)
+    prob = _ffi.Problem(ctx, A, b, c)
+
+    def tree():
+        t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=B, pool_capacity=1 << 15)
+        t.set_anchor_mode(True); t.set_dive(True)
+        st = t.stats()
+        while st['open_nodes'] < 6 * B:
+            st = t.solve(mip_gap=0.0, frontier_batch=B, max_steps=1)
+        return t
+    ref = tree()
+    end_ref = ref.solve(mip_gap=1e-4, frontier_batch=B)
+    t = tree()
+    with pytest.raises(_ffi.MipxError, match='no communicator'):
+        t.migrate_self(4)
+    t.keep_shard(0, 1)
+    t.set_comm(comm, 3)
+    N = t.stats()['open_nodes']
+    L0, U0, V0, D0 = t.peek_open(N)
+    key = lambda L, U, V, D: sorted((D[k], L[k].tobytes(), U[k].tobytes(), V[k].tobytes()) for k in range(len(D)))
+    moved = t.migrate_self(20)
+    assert moved == 20
+    L1, U1, V1, D1 = t.peek_open(N)
+    assert t.stats()['open_nodes'] == N and key(L0, U0, V0, D0) == key(L1, U1, V1, D1)   # the same records, bit for bit
+    assert t.migrate_self(10 ** 6) == min(4096, N // 2)   # every second node of the whole queue
+    L2, U2, V2, D2 = t.peek_open(N)
+    assert key(L0, U0, V0, D0) == key(L2, U2, V2, D2)
+    g = t.global_stats()
+    assert g['nodes_sent'] == g['nodes_received'] == 20 + min(4096, N // 2)
+    end = t.solve(mip_gap=1e-4, frontier_batch=B)
+    assert end['status'] == end_ref['status'] == 1 and abs(end['primal_bound'] - end_ref['primal_bound']) < 1e-9
+    assert abs(float(c @ t.solution()) - end['primal_bound']) < 1e-6
+    t.set_comm(None)
+    comm.close()
+
+
 def test_record_dual_bound_covers_the_steps_in_flight():
     """The exchange record's dual bound ([1]) includes the nodes popped into the steps in flight ([12]):
     read from a step hook (steps ARE in flight there) it never decreases and never exceeds the optimum,
@@ -112,7 +163,9 @@ def test_record_dual_bound_covers_the_steps_in_flight():
         assert st['status'] == 1 and abs(st['primal_bound'] - ref['primal_bound']) < 1e-9, (seed, st, ref)
         seen = np.array(seen)
         assert len(seen) > 3
-        assert np.all(np.diff(seen[:, 0]) >= 0), (seed, seen[:, 0])          # a proven bound never decreases
+        # a proven bound never decreases (1e-9: a child's LP value may undercut its parent's by rounding noise)
+        steps_down = np.diff(seen[:, 0])
+        assert np.all(steps_down >= -1e-9), (seed, steps_down[steps_down < 0], np.where(steps_down < 0)[0], len(seen))
         assert np.all(seen[:, 0] <= ref['primal_bound'] + 1e-9), (seed, seen[:, 0])
         assert np.all(seen[:, 0] <= seen[:, 2])                               # [1] includes [12]
         covered += int(np.sum(np.isfinite(seen[:, 2]) & (seen[:, 0] == seen[:, 2])))

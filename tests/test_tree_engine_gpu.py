@@ -418,7 +418,7 @@ def test_reanchored_step_matches_the_oracle(n, m, MB, K, target, depth, oracle):
     assert (t.peek_anchors(10 ** 6) >= 0).sum() >= K
     t2, _ = ramp()
     t2.solve(mip_gap=0.0, frontier_batch=MB, max_steps=1)
-    a, b2 = (x.solve(mip_gap=0.0, frontier_batch=256, max_steps=3) for x in (t, t2))
+    a, b2 = (x.solve(mip_gap=0.0, frontier_batch=min(256, MB), max_steps=3) for x in (t, t2))
     assert a['evaluated_nodes'] == b2['evaluated_nodes'] and isclose(a['dual_bound'], b2['dual_bound'], abs_tol=1e-7)
     if target >= 300:   # (deep enough: near the root the root's own tableau is the closer anchor)
         assert a['pivots'] < b2['pivots']
