@@ -17,6 +17,7 @@
 #include <queue>
 
 #include "tree_kernels.hip.h"
+#include "finish_kernels.hip.h"
 
 struct NodeRec {
     double key;          // queue key: dual bound (best first) or -depth (depth first)
@@ -247,6 +248,18 @@ struct StepBuf {
     int32_t *h_cs = nullptr;   // pinned: [counters (4) | state fields 0..6 + w_ncut (8 x max_batch)]
     int dive = 0;  // this step was launched with the in-place dive: children in a row per node
     bool scored_once = false;  // K4 ran on this step (the first run's request counter was zeroed by K1)
+    // the step finished on the device (finish_kernels.hip.h): the parents' records and the pool rows the
+    // children may take go up with the batch, a summary + compact lists come back
+    bool fast = false;
+    char *d_par = nullptr, *h_par = nullptr;     // [par_d (2 MB f64) | par_i (4 MB i32) | budget (per MB i32)]
+    int32_t *c_info = nullptr, *c_cnt = nullptr, *c_eval = nullptr, *c_flag = nullptr;
+    double *c_val = nullptr;
+    mipx::FinishSummary *d_sum = nullptr;
+    mipx::OpenEntry *d_open = nullptr;
+    int32_t *d_dead = nullptr;
+    mipx::PcSample *d_samples = nullptr, *h_samples = nullptr;   // h_samples: pinned staging of a host-finished step's samples
+    char *h_fin = nullptr;                       // pinned: [summary | table block | open entries | dead rows]
+    std::vector<int32_t> budget;
     int B = 0;
     bool in_flight = false;
     double inflight_min = std::numeric_limits<double>::infinity();   // lowest inherited bound of the batch (exchange record)
@@ -269,6 +282,17 @@ struct mipx_tree {
     double *d_cost_l = nullptr, *d_cost_r = nullptr, *d_cost_l2 = nullptr, *d_cost_r2 = nullptr;
     uint8_t *d_has = nullptr, *d_has2 = nullptr;
     char *h_tab = nullptr;  // pinned mirror of [cost_l | cost_r | has_entry]: d_cost_l .. d_has are one allocation
+    // the table block on the device: [cost_l | cost_r | has | pad | times_l | times_r | own sums (4 n)]; with the
+    // device finish the device holds the table (every sample reaches it through pc_apply, in stream order) and
+    // the host vectors are the snapshot read back with each step
+    size_t tab_off2 = 0, tab_bytes = 0;
+    int32_t *d_times = nullptr;
+    double *d_own = nullptr, *d_primal = nullptr;
+    double primal_sent = std::numeric_limits<double>::infinity();   // what the device knows of the host's incumbent value
+    bool fast_ok = false;           // steps are finished on the device where they file no probe request
+    bool times_dirty = false;       // the host replaced the table: times go up with it
+    size_t samples_cap = 0;
+    std::vector<mipx::PcSample> pend_samples;   // a host-finished step's samples, on their way to the device table
     hipStream_t st2 = nullptr;  // strong-branching probes + re-scoring run beside the step in flight
     hipStream_t st3 = nullptr;  // children records of step k are written beside the node LPs of step k+1
     hipEvent_t ev_child = nullptr;
@@ -495,7 +519,8 @@ void layout_pack(mipx_tree *t, StepBuf &S, int levels) {
     S.d_ask = (mipx::ScoreArgs::Ask *)((char *)S.d_pack + S.ask_off + 16);
 }
 
-int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false, bool no_ask = false) {
+int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false, bool no_ask = false, int side_stream = -1) {
+    const bool on_st2 = side_stream < 0 ? side : side_stream != 0;   // (default: the side tables go with the side stream)
     mipx::ScoreArgs s;
     s.n = t->n; s.n_int = t->n_int; s.batch = batch; s.rule = t->rule;
     s.int_idx = t->d_int_idx; s.x = S.d_x; s.status = S.d_status;
@@ -509,7 +534,7 @@ int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false, bool no
     if (!side && !no_ask && !(S.dive && batch == (S.dive + 1) * S.B && !S.scored_once))
         HIP_TRY(t->ctx, hipMemsetAsync(S.d_ask_count, 0, 16, t->ctx->stream));
     if (!no_ask) S.scored_once = true;
-    hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, side ? t->st2 : t->ctx->stream, s);
+    hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, on_st2 ? t->st2 : t->ctx->stream, s);
     HIP_TRY(t->ctx, hipGetLastError());
     return MIPX_OK;
 }
@@ -533,6 +558,49 @@ void pc_update(mipx_tree *t, int var, int dir, int lp_status, double objective, 
     times += 1;
     if (t->comm) t->pc_own[(dir ? 3 * n : 2 * n) + (size_t)var] += 1.0;
     t->has_entry[var] = 1;
+    if (t->fast_ok) {   // the device holds the table: the sample follows (pc_apply, tree_finish)
+        mipx::PcSample sm;
+        sm.var_dir = 2 * var + dir; sm.status = lp_status; sm.obj = objective; sm.bound = dual_bound; sm.vc = variable_change;
+        t->pend_samples.push_back(sm);
+    }
+}
+
+// the kernels that finish a step on the device, queued behind its scoring
+int launch_finish(mipx_tree *t, StepBuf &S) {
+    mipx_ctx *ctx = t->ctx;
+    hipStream_t st = ctx->stream;
+    const int B = S.B, L = t->dive + 1;
+    const size_t MB = (size_t)t->max_batch;
+    mipx::FinishArgs g;
+    g.n = t->n; g.m = t->m; g.B = B; g.dive = S.dive; g.rule = t->rule;
+    g.status = S.d_status; g.bidx = S.d_bidx; g.mipf = S.d_mipf; g.nprobe = S.d_nprobe; g.npiv = S.d_npiv;
+    g.dvar = S.d_dvar; g.ddir = S.d_ddir; g.obj = S.d_obj; g.bval = S.d_bval; g.dval = S.d_dval;
+    g.ask_count = S.d_ask_count; g.vout = S.d_vout;
+    g.slot = S.d_slot;
+    g.par_d = (const double *)S.d_par;
+    g.par_i = (const int32_t *)(S.d_par + 2 * (size_t)B * 8);
+    g.budget = g.par_i + 4 * (size_t)B;
+    g.pool_l = t->pool_l; g.pool_u = t->pool_u; g.pool_v = t->pool_v; g.primal = t->d_primal;
+    g.c_info = S.c_info; g.c_cnt = S.c_cnt; g.c_eval = S.c_eval; g.c_val = S.c_val; g.c_flag = S.c_flag;
+    g.sum = S.d_sum; g.open = S.d_open; g.dead = S.d_dead; g.samples = S.d_samples;
+    (void)L;
+    g.c_run = S.c_val + 2 * MB;
+    hipLaunchKernelGGL(mipx::finish_candidates, dim3((B + 255) / 256), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(mipx::finish_prefix_min, dim3(1), dim3(1024), 0, st, g);
+    hipLaunchKernelGGL(mipx::finish_decide, dim3((B + 255) / 256), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(mipx::finish_scan, dim3(1), dim3(1024), 0, st, g);
+    if (t->n <= 256) hipLaunchKernelGGL((mipx::finish_write<1>), dim3(B), dim3(256), 0, st, g);
+    else if (t->n <= 512) hipLaunchKernelGGL((mipx::finish_write<2>), dim3(B), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((mipx::finish_write<4>), dim3(B), dim3(256), 0, st, g);
+    if (t->rule == 1) {
+        hipLaunchKernelGGL(mipx::finish_samples, dim3((B + 255) / 256), dim3(256), 0, st, g);
+        mipx::PcApplyArgs a;
+        a.n = t->n; a.sum = S.d_sum; a.count = -1; a.samples = S.d_samples;
+        a.cost_l = t->d_cost_l; a.cost_r = t->d_cost_r; a.has = t->d_has; a.times = t->d_times; a.own = t->d_own;
+        hipLaunchKernelGGL(mipx::pc_apply, dim3(2 * t->n), dim3(64), 0, st, a);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return MIPX_OK;
 }
 
 // First half of a step: pop the batch and enqueue its node LPs + scoring (no host wait).
@@ -593,7 +661,35 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
         std::memcpy(ht + n * 8, t->cost_r.data(), n * 8);
         std::memcpy(ht + 2 * n * 8, t->has_entry.data(), n);
         HIP_TRY(ctx, hipMemcpyAsync(t->d_cost_l, ht, 17 * n, hipMemcpyHostToDevice, st));
+        if (t->fast_ok && t->times_dirty) {   // (the host replaced the table: an exchange, mipx_tree_set_pseudo_costs)
+            char *tt = t->h_tab + 4 * 17 * n + (size_t)(t->steps & 3) * 8 * n;
+            std::memcpy(tt, t->times_l.data(), n * 4);
+            std::memcpy(tt + n * 4, t->times_r.data(), n * 4);
+            HIP_TRY(ctx, hipMemcpyAsync(t->d_times, tt, 8 * n, hipMemcpyHostToDevice, st));
+            t->times_dirty = false;
+        }
         t->table_dirty = false;
+    }
+    S.fast = t->fast_ok && !t->trace;
+    if (S.fast) {
+        if (t->primal < t->primal_sent) {   // the host knows a better incumbent than the device (exchange, host-finished step)
+            hipLaunchKernelGGL(mipx::primal_lower, dim3(1), dim3(1), 0, st, t->d_primal, t->primal);
+            t->primal_sent = t->primal;
+        }
+        // the parents' records and the pool rows the children may take: chain k, level p, direction d owns
+        // budget[k][2 p + d] (the claim batch_size() left room for, handed out up front)
+        const size_t per = 2 * (1 + (size_t)t->dive), need = per * (size_t)B;
+        S.budget.assign(t->free_slots.end() - (std::ptrdiff_t)need, t->free_slots.end());
+        t->free_slots.resize(t->free_slots.size() - need);
+        double *pd = (double *)S.h_par;
+        int32_t *pi = (int32_t *)(S.h_par + 2 * (size_t)B * 8);
+        for (int k = 0; k < B; k++) {
+            const NodeRec &nd = S.recs[(size_t)k];
+            pd[k] = nd.dual_bound; pd[B + k] = nd.b_val;
+            pi[k] = nd.b_idx; pi[B + k] = nd.b_dir; pi[2 * B + k] = nd.depth; pi[3 * B + k] = nd.anchor;
+        }
+        std::memcpy(pi + 4 * (size_t)B, S.budget.data(), need * 4);
+        HIP_TRY(ctx, hipMemcpyAsync(S.d_par, S.h_par, 2 * (size_t)B * 8 + (4 * (size_t)B + need) * 4, hipMemcpyHostToDevice, st));
     }
     std::memcpy(S.h_slot, slots.data(), (size_t)B * 4);
     for (int k = 0; k < B; k++) S.h_slot[B + k] = S.recs[(size_t)k].anchor;  // [pool rows | anchor-table entries]
@@ -638,6 +734,7 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(S.e1, st));
     if ((rc = launch_score(t, S, (S.dive + 1) * B))) return rc;
+    if (S.fast && (rc = launch_finish(t, S))) return rc;
     HIP_TRY(ctx, hipEventRecord(S.done, st));
     return MIPX_OK;
 }
@@ -780,6 +877,94 @@ int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
     return MIPX_OK;
 }
 
+// The table block as the device holds it -> the host's vectors (a snapshot: x_fill_record, the API, the
+// re-scoring of a host-finished step read them).
+void table_snapshot(mipx_tree *t, const char *blk) {
+    const size_t n = (size_t)t->n;
+    std::memcpy(t->cost_l.data(), blk, n * 8);
+    std::memcpy(t->cost_r.data(), blk + n * 8, n * 8);
+    std::memcpy(t->has_entry.data(), blk + 16 * n, n);
+    std::memcpy(t->times_l.data(), blk + t->tab_off2, n * 4);
+    std::memcpy(t->times_r.data(), blk + t->tab_off2 + n * 4, n * 4);
+    if (t->comm) std::memcpy(t->pc_own.data(), blk + t->tab_off2 + 8 * n, 4 * n * 8);
+}
+
+// Second half of a step the device finished (finish_kernels.hip.h): counters, the new open nodes into the
+// node table and the queue, the free rows back, the incumbent, the table snapshot.
+int tree_finish_fast(mipx_tree *t, StepBuf &S, const mipx::FinishSummary &sum) {
+    mipx_ctx *ctx = t->ctx;
+    const int B = S.B, n = t->n;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto tp = now();
+    t->lps += B + sum.dives;
+    t->dives += sum.dives;
+    t->evaluated += sum.evaluated;
+    t->pivots += sum.pivots;
+    t->closed_min = std::fmin(t->closed_min, sum.closed_min);
+    if (sum.unbounded) t->unbounded = true;
+    const size_t per = 2 * (1 + (size_t)t->dive);
+    if (sum.n_open < 0 || (size_t)sum.n_open > per * (size_t)B || sum.n_dead < 0 || (size_t)sum.n_dead > per * (size_t)B ||
+        (size_t)sum.n_open + (size_t)sum.n_dead != per * (size_t)B)
+        return fail(ctx, MIPX_EHIP, "tree: the device finish returned an inconsistent summary");
+    char *hp = S.h_fin + 128;
+    const bool tab = t->rule == 1;
+    mipx::OpenEntry *open = (mipx::OpenEntry *)(hp + (t->tab_bytes + 31) / 32 * 32);
+    int32_t *dead = (int32_t *)(open + per * (size_t)t->max_batch);
+    if (tab) HIP_TRY(ctx, hipMemcpyAsync(hp, t->d_cost_l, t->tab_bytes, hipMemcpyDeviceToHost, t->st2));
+    if (sum.n_open > 0)
+        HIP_TRY(ctx, hipMemcpyAsync(open, S.d_open, (size_t)sum.n_open * sizeof(mipx::OpenEntry), hipMemcpyDeviceToHost, t->st2));
+    if (sum.n_dead > 0)
+        HIP_TRY(ctx, hipMemcpyAsync(dead, S.d_dead, (size_t)sum.n_dead * 4, hipMemcpyDeviceToHost, t->st2));
+    HIP_TRY(ctx, hipStreamSynchronize(t->st2));
+    t->phase_ms[1] += std::chrono::duration<double, std::milli>(now() - tp).count(); tp = now();
+    if (tab) table_snapshot(t, hp);
+    // the new open nodes, in the order the host loop created them (chain by chain, level by level, left
+    // then right)
+    const bool defer_push = t->use_bq && t->search == 0;
+    t->pend.clear();
+    for (int q = 0; q < sum.n_open; q++) {
+        const mipx::OpenEntry &e = open[q];
+        NodeRec c;
+        c.dual_bound = e.key;
+        c.depth = e.depth;
+        c.key = t->search == 0 ? e.key : -(double)e.depth;
+        c.b_idx = e.bidx_dir >> 1; c.b_dir = e.bidx_dir & 1; c.b_val = e.bval;
+        c.born = (int32_t)t->steps; c.anchor = e.anchor; c.ncut = 0; c.slot = e.slot;
+        t->nodes.push_back(c);
+        const int64_t cid = (int64_t)t->nodes.size() - 1;
+        if (defer_push) t->pend.push_back({c.key, cid});
+        else tree_push(t, cid);
+    }
+    if (defer_push) t->bq.push_many(t->pend.data(), t->pend.size());
+    // rows free again: the budget rows that hold no open node, the batch's own rows
+    t->free_slots.insert(t->free_slots.end(), dead, dead + sum.n_dead);
+    t->free_slots.insert(t->free_slots.end(), S.slots.begin(), S.slots.begin() + B);
+    S.budget.clear();
+    t->phase_ms[3] += std::chrono::duration<double, std::milli>(now() - tp).count(); tp = now();
+    t->primal_sent = std::fmin(t->primal_sent, sum.primal);
+    if (sum.incumbent_pos >= 0 && sum.primal < t->primal) {
+        t->primal = sum.primal;
+        int rc = tree_d2h(t, t->best_x.data(), S.d_x + (size_t)sum.incumbent_pos * n, (size_t)n * 8);
+        if (rc) return rc;
+        t->have_x = true;
+    }
+    // anchor mode: the root's optimal tableau (a root that needed no probe comes this way)
+    if (t->anchor_mode && !t->anchor_set && S.ids[0] == 0) {
+        int32_t st0 = -1;
+        int rc = tree_d2h(t, &st0, S.d_status, 4);
+        if (rc) return rc;
+        if (st0 == 0) {
+            std::vector<int8_t> rootv((size_t)t->n + t->m);
+            HIP_TRY(ctx, hipMemcpy(rootv.data(), S.d_vout, rootv.size(), hipMemcpyDeviceToHost));
+            const int arc = mipx_problem_set_anchor(t->prob, rootv.data());
+            if (arc) return arc;
+            t->anchor_set = true;
+        }
+    }
+    t->phase_ms[4] += std::chrono::duration<double, std::milli>(now() - tp).count();
+    return MIPX_OK;
+}
+
 // Second half: wait for that batch only, then the reference's bookkeeping and the children.
 int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     mipx_ctx *ctx = t->ctx;
@@ -802,6 +987,14 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, S.e0, S.e1) == hipSuccess) t->kernel_ms += ms;
+    }
+    if (S.fast) {
+        mipx::FinishSummary *hs = (mipx::FinishSummary *)S.h_fin;
+        if ((rc = tree_d2h(t, hs, S.d_sum, sizeof(mipx::FinishSummary)))) return rc;
+        if (!hs->host_path) return tree_finish_fast(t, S, *hs);
+        // probe requests: the host finishes this step; the rows handed out for its children come back
+        t->free_slots.insert(t->free_slots.end(), S.budget.begin(), S.budget.end());
+        S.budget.clear();
     }
     // one copy (pinned destination) for everything the host reads per node
     if ((rc = tree_d2h(t, S.h_pack, S.d_pack, S.pack_bytes))) return rc;
@@ -955,19 +1148,35 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
                 e += 0;
             }
         }
-        if (changed) t->table_dirty = true;
+        if (changed && !t->fast_ok) t->table_dirty = true;   // (device finish: the samples go to the device table below)
         // re-score with the updated table: always in the sequential mode (the reference branches
         // with the table its own node just updated); when steps overlap, only if probes created
         // entries that the first scoring had to leave out (the wait covers the step in flight)
         t->phase_ms[6] += ms_since(tp); tp = now();
+        if (t->fast_ok && !t->pend_samples.empty()) {
+            // the device holds the table: this step's samples reach it in the order they were applied here
+            const size_t cnt = t->pend_samples.size();
+            if (cnt > t->samples_cap) return fail(ctx, MIPX_ENOMEM, "tree: more pseudo-cost samples than the staging holds");
+            std::memcpy(S.h_samples, t->pend_samples.data(), cnt * sizeof(mipx::PcSample));
+            t->pend_samples.clear();
+            HIP_TRY(ctx, hipMemcpyAsync(S.d_samples, S.h_samples, cnt * sizeof(mipx::PcSample), hipMemcpyHostToDevice, st));
+            mipx::PcApplyArgs pa;
+            pa.n = n; pa.sum = nullptr; pa.count = (int)cnt; pa.samples = S.d_samples;
+            pa.cost_l = t->d_cost_l; pa.cost_r = t->d_cost_r; pa.has = t->d_has; pa.times = t->d_times; pa.own = t->d_own;
+            hipLaunchKernelGGL(mipx::pc_apply, dim3(2 * n), dim3(64), 0, st, pa);
+            HIP_TRY(ctx, hipGetLastError());
+        }
         if (changed && (!overlapped || total > 0)) {
-            double *cl = use_side ? t->d_cost_l2 : t->d_cost_l, *cr = use_side ? t->d_cost_r2 : t->d_cost_r;
-            uint8_t *ch = use_side ? t->d_has2 : t->d_has;
+            // (device finish: the re-scoring reads copies of the host's snapshot + this step's updates, the device
+            // table itself only ever changes through pc_apply)
+            const bool side_tab = use_side || t->fast_ok;
+            double *cl = side_tab ? t->d_cost_l2 : t->d_cost_l, *cr = side_tab ? t->d_cost_r2 : t->d_cost_r;
+            uint8_t *ch = side_tab ? t->d_has2 : t->d_has;
             HIP_TRY(ctx, hipMemcpyAsync(cl, t->cost_l.data(), (size_t)n * 8, hipMemcpyHostToDevice, ps));
             HIP_TRY(ctx, hipMemcpyAsync(cr, t->cost_r.data(), (size_t)n * 8, hipMemcpyHostToDevice, ps));
             HIP_TRY(ctx, hipMemcpyAsync(ch, t->has_entry.data(), (size_t)n, hipMemcpyHostToDevice, ps));
-            if (!use_side) t->table_dirty = false;
-            if ((rc = launch_score(t, S, NB, use_side))) return rc;
+            if (!side_tab) t->table_dirty = false;
+            if ((rc = launch_score(t, S, NB, side_tab, false, use_side ? 1 : 0))) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ps));
             if ((rc = tree_d2h(t, bidx, S.d_bidx, (size_t)NB * 4))) return rc;
             if ((rc = tree_d2h(t, bval, S.d_bval, (size_t)NB * 8))) return rc;
@@ -1427,6 +1636,7 @@ int x_apply(mipx_tree *t, const char *gathered, bool last) {
             t->has_entry[j] = (tl > 0 || tr > 0) ? 1 : 0;
         }
         t->table_dirty = true;
+        t->times_dirty = true;
     }
     t->x_rounds++;
     if (last) return MIPX_OK;
@@ -1618,13 +1828,41 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
         if (hipEventCreate(&S.e0) != hipSuccess || hipEventCreate(&S.e1) != hipSuccess ||
             hipEventCreate(&S.done) != hipSuccess) rc |= MIPX_EHIP;
     }
-    {   // [cost_l | cost_r | has_entry] in one allocation: one upload per step
+    {   // [cost_l | cost_r | has_entry] in one allocation: one upload per step; behind them (device finish)
+        // [times_l | times_r | own sums]
         char *tab = nullptr;
-        rc |= dmalloc(ctx, &tab, 17 * n);
+        t->tab_off2 = (17 * n + 7) / 8 * 8;
+        t->tab_bytes = t->tab_off2 + 8 * n + 32 * n;
+        rc |= dmalloc(ctx, &tab, t->tab_bytes);
         t->d_cost_l = (double *)tab;
         t->d_cost_r = tab ? (double *)(tab + 8 * n) : nullptr;
         t->d_has = tab ? (uint8_t *)(tab + 16 * n) : nullptr;
-        if (hipHostMalloc((void **)&t->h_tab, 4 * 17 * n, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
+        t->d_times = tab ? (int32_t *)(tab + t->tab_off2) : nullptr;
+        t->d_own = tab ? (double *)(tab + t->tab_off2 + 8 * n) : nullptr;
+        if (hipHostMalloc((void **)&t->h_tab, 4 * 17 * n + 4 * 8 * n, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
+        rc |= dmalloc(ctx, &t->d_primal, 1);
+    }
+    // Steps are finished on the device (finish_kernels.hip.h) in the batched modes without cut rounds;
+    // MIPX_HOST_FINISH=1 keeps the host loop (A/B runs).  The exact mode (max_batch = 1) reproduces the
+    // reference's node order on the host.
+    t->fast_ok = max_batch > 1 && !t->cuts && !(std::getenv("MIPX_HOST_FINISH") && std::atoi(std::getenv("MIPX_HOST_FINISH")) != 0);
+    if (t->fast_ok) {
+        const size_t per = 2 * LC;
+        t->samples_cap = (size_t)t->probe_cap + LC * B;
+        for (StepBuf &S : t->buf) {
+            const size_t par_bytes = 2 * B * 8 + (4 * B + per * B) * 4;
+            rc |= dmalloc(ctx, &S.d_par, par_bytes);
+            rc |= dmalloc(ctx, &S.c_info, B); rc |= dmalloc(ctx, &S.c_cnt, 3 * B); rc |= dmalloc(ctx, &S.c_eval, 2 * B);
+            rc |= dmalloc(ctx, &S.c_flag, B); rc |= dmalloc(ctx, &S.c_val, 3 * B);
+            rc |= dmalloc(ctx, &S.d_sum, 1);
+            rc |= dmalloc(ctx, &S.d_open, per * B); rc |= dmalloc(ctx, &S.d_dead, per * B);
+            rc |= dmalloc(ctx, &S.d_samples, t->samples_cap);
+            const size_t fin_bytes = 128 + (t->tab_bytes + 31) / 32 * 32 + per * B * (sizeof(mipx::OpenEntry) + 4);
+            if (hipHostMalloc((void **)&S.h_par, par_bytes, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void **)&S.h_fin, fin_bytes, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void **)&S.h_samples, t->samples_cap * sizeof(mipx::PcSample), hipHostMallocDefault) != hipSuccess)
+                rc |= MIPX_EHIP;
+        }
     }
     if (branch_rule == 1) {
         rc |= dmalloc(ctx, &t->pp_l, pc * n); rc |= dmalloc(ctx, &t->pp_u, pc * n);
@@ -1638,9 +1876,11 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
     t->has_entry.assign(n, 0);
     t->best_x.assign(n, 0.0);
     HIP_TRY(ctx, hipMemcpy(t->d_int_idx, int_idx, (size_t)n_int * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemset(t->d_cost_l, 0, n * 8));
-    HIP_TRY(ctx, hipMemset(t->d_cost_r, 0, n * 8));
-    HIP_TRY(ctx, hipMemset(t->d_has, 0, n));
+    HIP_TRY(ctx, hipMemset(t->d_cost_l, 0, t->tab_bytes));   // costs, entries, times, own sums
+    {
+        const double inf_ = std::numeric_limits<double>::infinity();
+        HIP_TRY(ctx, hipMemcpy(t->d_primal, &inf_, 8, hipMemcpyHostToDevice));
+    }
     // root record in slot 0: cold start (all status codes 0 -> slack basis, sides from d_j)
     HIP_TRY(ctx, hipMemcpy(t->pool_l, l, n * 8, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(t->pool_u, u, n * 8, hipMemcpyHostToDevice));
@@ -1693,6 +1933,15 @@ void mipx_tree_destroy(mipx_tree *t) {
                     t->d_cost_l2, t->d_cost_r2, t->d_has2, t->pp_l, t->pp_u, t->pp_v, t->pp_obj, t->pp_status};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    if (t->d_primal) (void)hipFree(t->d_primal);
+    for (StepBuf &S : t->buf) {
+        void *fp[] = {S.d_par, S.c_info, S.c_cnt, S.c_eval, S.c_flag, S.c_val, S.d_sum, S.d_open, S.d_dead, S.d_samples};
+        for (void *q : fp)
+            if (q) (void)hipFree(q);
+        if (S.h_par) (void)hipHostFree(S.h_par);
+        if (S.h_fin) (void)hipHostFree(S.h_fin);
+        if (S.h_samples) (void)hipHostFree(S.h_samples);
+    }
     for (StepBuf &S : t->buf) {
         void *sp[] = {S.d_slot, S.d_iters, S.d_pack, S.d_plist, S.d_x, S.d_vout};
         for (void *q : sp)
@@ -1792,7 +2041,8 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
         // in place branches too); the steps in flight have the same claim.  When the pool cannot take
         // a single node's children the search stops (status 4, stats.pool_exhausted).
         const int64_t per = 2 * (1 + (int64_t)t->dive);
-        const int64_t room = ((int64_t)t->free_slots.size() - per * inflight) / per;
+        // (device finish: the steps in flight took their rows out of the free list when they were launched)
+        const int64_t room = ((int64_t)t->free_slots.size() - (t->fast_ok ? 0 : per * inflight)) / per;
         if (room < want) {
             want = room > 0 ? room : 0;
             if (want == 0 && inflight == 0) {
@@ -2046,6 +2296,10 @@ int mipx_tree_set_comm(mipx_tree *t, mipx_comm *c, int every_steps) {
         t->pc_base[2 * n + j] = (double)t->times_l[j];
         t->pc_base[3 * n + j] = (double)t->times_r[j];
     }
+    if (t->fast_ok) {   // (nothing is in flight between two solves)
+        HIP_TRY(t->ctx, hipStreamSynchronize(t->ctx->stream));
+        HIP_TRY(t->ctx, hipMemset(t->d_own, 0, 4 * n * 8));
+    }
     t->g_dual = tree_dual_bound(t);
     for (int k = 0; k < 4; k++) t->g_counts[k] = t->ramp[k];
     t->g_counts[4] = tree_open_count(t);
@@ -2144,6 +2398,7 @@ int mipx_tree_set_pseudo_costs(mipx_tree *t, const double *cost_l, const double 
     std::memcpy(t->times_r.data(), times_r, (size_t)t->n * 4);
     for (int j = 0; j < t->n; j++) t->has_entry[j] = (times_l[j] > 0 || times_r[j] > 0) ? 1 : 0;
     t->table_dirty = true;
+    t->times_dirty = true;
     return MIPX_OK;
 }
 

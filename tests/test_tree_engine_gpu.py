@@ -472,3 +472,68 @@ def test_example_models_batched_mode_with_defaults(Node):
         x = bb.solution
         idx = bb.model.integerIndices
         assert np.max(np.abs(x[idx] - np.round(x[idx]))) <= 1e-4, f
+
+
+@pytest.mark.parametrize('n,m,B,dive,rule,search,steps', [
+    (64, 32, 256, 1, 'pseudo cost', 'best first', 25),
+    (64, 32, 256, 8, 'pseudo cost', 'best first', 25),
+    (64, 32, 64, 4, 'most fractional', 'best first', 25),
+    (40, 16, 16, 3, 'pseudo cost', 'depth first', 60),
+    (256, 128, 512, 8, 'pseudo cost', 'best first', 40),
+    (300, 150, 64, 4, 'pseudo cost', 'best first', 40)])    # (the HBM-streaming kernel)
+def test_device_finish_matches_the_host_loop(n, m, B, dive, rule, search, steps):
+    """The device finish (csrc/finish_kernels.hip.h: decisions, child records, compact open list, free
+    rows, pseudo-cost recurrence as kernels) against the host loop it replaces (MIPX_HOST_FINISH=1: the
+    restatement of branch_and_bound.py:243-266 / pseudo_cost.py:68-100 this engine was pinned with), one
+    step per call so that both see the same table at every launch: after every step the same counters,
+    bounds, open-node count and -- bit for bit -- the same pseudo-cost table; at the end the same open
+    nodes (bounds, bases, inherited bounds)."""
+    from simple_mip_solver_amd import _ffi
+    ctx = _ffi.default_context()
+    A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=1)
+    probs = []
+
+    def make(host):
+        old = os.environ.pop('MIPX_HOST_FINISH', None)
+        if host:
+            os.environ['MIPX_HOST_FINISH'] = '1'
+        probs.append(_ffi.Problem(ctx, A, b, c))     # (a problem of its own: the root's anchor belongs to the problem)
+        try:
+            t = _ffi.Tree(probs[-1], ints, l, u, branch_rule=rule, search_rule=search, max_batch=B, pool_capacity=1 << 15)
+        finally:
+            os.environ.pop('MIPX_HOST_FINISH', None)
+            if old is not None:
+                os.environ['MIPX_HOST_FINISH'] = old
+        t.set_anchor_mode(True)
+        t.set_dive(dive)
+        return t
+    dev, host = make(False), make(True)
+    keys = ('evaluated_nodes', 'lp_solved', 'probes_solved', 'pivots', 'open_nodes', 'steps', 'dives', 'dual_bound',
+            'primal_bound', 'status')
+    fast_steps, prev = 0, 0
+    for step in range(steps):
+        a = dev.solve(mip_gap=1e-4, frontier_batch=B, max_steps=1)
+        h = host.solve(mip_gap=1e-4, frontier_batch=B, max_steps=1)
+        assert {k: a[k] for k in keys} == {k: h[k] for k in keys}, (step, a, h)
+        pa, ph = dev.pseudo_cost_arrays(), host.pseudo_cost_arrays()
+        for x, y in zip(pa, ph):
+            assert np.array_equal(x, y), step
+        fast_steps += a['probes_solved'] == prev    # (no probe request in the step: the device finished it)
+        prev = a['probes_solved']
+        if a['status'] != 4:
+            break
+    assert fast_steps > 0      # steps without probe requests did go through the device finish
+    N = a['open_nodes']
+    if N:
+        key = lambda r: sorted((r[3][k], r[0][k].tobytes(), r[1][k].tobytes(), r[2][k].tobytes()) for k in range(len(r[3])))
+        assert key(dev.peek_open(N)) == key(host.peek_open(N))
+    if a['primal_bound'] < float('inf'):
+        assert np.array_equal(dev.solution(), host.solution())
+    # and pipelined (steps overlap, the table a launch sees is fresher on the device): the same optimum
+    if (n, m) == (40, 16):
+        ends = [t.solve(mip_gap=1e-4, frontier_batch=B) for t in (dev, host)]
+        assert ends[0]['status'] == ends[1]['status'] == 1
+        assert isclose(ends[0]['primal_bound'], ends[1]['primal_bound'], abs_tol=1e-9)
+    dev.close(); host.close()
+    for p in probs:
+        p.close()
