@@ -52,10 +52,11 @@ struct FinishSummary {
     int32_t host_path;           // 1: probe requests were filed -- the host path finishes the step
     int32_t n_open, n_dead, n_samples;
     int32_t unbounded, incumbent_pos;   // output position of the step's best improving integral node, -1: none
+    int32_t n_deferred, pad0;           // nodes that filed probe requests: left to the host, after everything else
     int64_t evaluated, dives, pivots;
     double closed_min, primal;   // lowest value among the step's closed leaves; the incumbent value after the step
     double primal_before;        // ... and before it: what the step's decisions compared against
-    int64_t pad[7];
+    int64_t pad[6];
 };
 static_assert(sizeof(FinishSummary) == 128, "FinishSummary layout");
 
@@ -65,6 +66,7 @@ struct FinishArgs {
     const int32_t *status, *bidx, *mipf, *nprobe, *npiv, *dvar, *ddir;
     const double *obj, *bval, *dval;
     const int32_t *ask_count;
+    int ask_cap;                 // more requests than the compact list holds (the ramp-up): the whole step is the host's
     const int8_t *vout;          // (dive + 1) * B x (n + m): the basis every LP ended with
     // the batch: pool rows, the parents' records (dense by batch position), the rows its children may take
     const int32_t *slot;         // B
@@ -136,14 +138,15 @@ __device__ inline int chain_samples(const FinishArgs &g, int k, double primal, P
 // exclusive prefix minimum.
 __global__ __launch_bounds__(256) void finish_candidates(FinishArgs g) {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (*g.ask_count > 0) {
+    if (*g.ask_count > g.ask_cap) {
         if (k == 0) g.sum->host_path = 1;
         return;
     }
     if (k == 0) { g.sum->host_path = 0; g.sum->primal_before = *g.primal; }
     if (k >= g.B) return;
     double cand = __builtin_huge_val();
-    for (int pos = k;; pos += g.B) {
+    // (a node that filed probe requests is the host's: it comes after every other chain of the step)
+    for (int pos = k; g.nprobe[k] == 0; pos += g.B) {
         if (!lp_feasible_code(g.status[pos])) break;
         if (g.mipf[pos]) { cand = g.obj[pos]; break; }
         const bool take_dive = chain_dived(g, pos);
@@ -185,7 +188,8 @@ __global__ __launch_bounds__(256) void finish_decide(FinishArgs g) {
     const int per = 2 * (1 + g.dive);
     int nbranch = 0, nopen = 0, took_last = 0, evaluated = 0, pivots = 0, unbounded = 0, cand_level = 0;
     double closed = INF, cand = INF;
-    for (int level = 0, pos = k;; level++, pos += g.B) {
+    const bool deferred = g.nprobe[k] > 0;
+    for (int level = 0, pos = k; !deferred; level++, pos += g.B) {
         const int st = g.status[pos];
         const bool feas = lp_feasible_code(st);
         evaluated++;
@@ -209,10 +213,11 @@ __global__ __launch_bounds__(256) void finish_decide(FinishArgs g) {
         if (!branched) closed = fmin(closed, feas ? g.obj[pos] : INF);
         if (!go_on) break;
     }
-    g.c_info[k] = nbranch | (took_last << 8);
+    g.c_info[k] = nbranch | (took_last << 8) | (deferred ? 1 << 9 : 0);
     g.c_cnt[k] = nopen;
     g.c_cnt[g.B + k] = per - nopen;
-    g.c_cnt[2 * g.B + k] = chain_samples(g, k, g.sum->primal_before, nullptr);   // (section 3 runs before the walk: the step's starting value)
+    // (section 3 runs before the walk: the step's starting value)
+    g.c_cnt[2 * g.B + k] = deferred ? 0 : chain_samples(g, k, g.sum->primal_before, nullptr);
     g.c_eval[k] = evaluated;
     g.c_eval[g.B + k] = pivots;
     g.c_val[k] = closed;
@@ -236,6 +241,7 @@ __global__ __launch_bounds__(1024) void finish_scan(FinishArgs g) {
     double closed = INF, cand = INF;
     int ord = 0x7fffffff, unb = 0;
     for (int k = k0; k < k1; k++) {
+        unb += (g.c_info[k] >> 9 & 1) << 1;    // (bit 0: unbounded flag; above it: the count of deferred nodes)
         for (int f = 0; f < 3; f++) loc[f] += g.c_cnt[f * B + k];
         ev += g.c_eval[k];
         pv += g.c_eval[B + k];
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(1024) void finish_scan(FinishArgs g) {
             s_val[0][t] = fmin(s_val[0][t], s_val[0][t + d]);
             const double a = s_val[1][t], b = s_val[1][t + d];
             if (b < a || (b == a && s_ord[t + d] < s_ord[t])) { s_val[1][t] = b; s_ord[t] = s_ord[t + d]; }
-            s_unb[t] |= s_unb[t + d];
+            s_unb[t] = ((s_unb[t] | s_unb[t + d]) & 1) | ((s_unb[t] >> 1) + (s_unb[t + d] >> 1)) << 1;
         }
         __syncthreads();
     }
@@ -281,9 +287,10 @@ __global__ __launch_bounds__(1024) void finish_scan(FinishArgs g) {
         FinishSummary *s = g.sum;
         s->n_open = s_cnt[0][1023]; s->n_dead = s_cnt[1][1023]; s->n_samples = s_cnt[2][1023];
         s->evaluated = s_ev[0][0]; s->pivots = s_ev[1][0];
-        s->dives = s_ev[0][0] - B;
+        s->n_deferred = s_unb[0] >> 1;
+        s->dives = s_ev[0][0] - (B - s->n_deferred);
         s->closed_min = s_val[0][0];
-        s->unbounded = s_unb[0];
+        s->unbounded = s_unb[0] & 1;
         const double best = s_val[1][0], old = *g.primal;
         if (best < old) {
             const int kk = s_ord[0];
@@ -381,6 +388,7 @@ __global__ __launch_bounds__(256) void finish_samples(FinishArgs g) {
     if (g.sum->host_path || g.rule != 1) return;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= g.B) return;
+    if (g.nprobe[k] > 0) return;
     chain_samples(g, k, g.sum->primal_before, g.samples + g.c_cnt[2 * g.B + k]);
 }
 
@@ -404,25 +412,33 @@ __global__ __launch_bounds__(64) void pc_apply(PcApplyArgs a) {
     int times = a.times[dir * n + var];
     double own_sum = a.own[dir * n + var], own_t = a.own[(2 + dir) * n + var];
     bool any = false;
-    for (int base = 0; base < cnt; base += 64) {
-        const int i = base + lane;
-        const int key = i < cnt ? a.samples[i].var_dir : -1;
-        unsigned long long mask = __ballot(key == vd);
-        while (mask) {
-            const int j = __ffsll((long long)mask) - 1;
-            mask &= mask - 1ull;
-            const PcSample s = a.samples[base + j];
-            if (s.status == 0 || s.status == 3) {
-                double bc = s.obj - s.bound;
-                if (bc < 0) bc = 0;
-                cost = (cost * (double)times + bc / s.vc) / (double)(times + 1);
-                own_sum += bc / s.vc;
-            } else {
-                own_sum += cost;
+    for (int base0 = 0; base0 < cnt; base0 += 256) {
+        int key[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {   // four loads in flight per lane: the walk is bound by their latency
+            const int i = base0 + 64 * c + lane;
+            key[c] = i < cnt ? a.samples[i].var_dir : -1;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int base = base0 + 64 * c;
+            unsigned long long mask = __ballot(key[c] == vd);
+            while (mask) {
+                const int j = __ffsll((long long)mask) - 1;
+                mask &= mask - 1ull;
+                const PcSample s = a.samples[base + j];
+                if (s.status == 0 || s.status == 3) {
+                    double bc = s.obj - s.bound;
+                    if (bc < 0) bc = 0;
+                    cost = (cost * (double)times + bc / s.vc) / (double)(times + 1);
+                    own_sum += bc / s.vc;
+                } else {
+                    own_sum += cost;
+                }
+                times += 1;
+                own_t += 1.0;
+                any = true;
             }
-            times += 1;
-            own_t += 1.0;
-            any = true;
         }
     }
     if (any && lane == 0) {
@@ -433,6 +449,29 @@ __global__ __launch_bounds__(64) void pc_apply(PcApplyArgs a) {
         a.own[(2 + dir) * n + var] = own_t;
         a.has[var] = 1;
     }
+}
+
+// An exchange between ranks: what the OTHER ranks sampled since the last exchange joins the table in sum
+// form -- mean <- (mean * times + sum) / (times + count) -- without touching this rank's own running
+// recurrence (its samples of the steps in flight are in the table already).
+struct PcMergeArgs {
+    int n;
+    const double *delta;         // [sum_l | sum_r | times_l | times_r], n each
+    double *cost_l, *cost_r;
+    uint8_t *has;
+    int32_t *times;
+};
+__global__ __launch_bounds__(256) void pc_merge(PcMergeArgs a) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 2 * a.n) return;
+    const int dir = e / a.n, var = e - dir * a.n;
+    const double ds = a.delta[dir * a.n + var], dt = a.delta[(2 + dir) * a.n + var];
+    if (!(dt > 0.0)) return;
+    double *cost = dir ? a.cost_r : a.cost_l;
+    const int t0 = a.times[dir * a.n + var];
+    cost[var] = (cost[var] * (double)t0 + ds) / ((double)t0 + dt);
+    a.times[dir * a.n + var] = t0 + (int)dt;
+    a.has[var] = 1;
 }
 
 // the host lowered the incumbent (an exchange, mipx_tree_set_primal_bound, a step finished by the host)

@@ -251,6 +251,8 @@ struct StepBuf {
     // the step finished on the device (finish_kernels.hip.h): the parents' records and the pool rows the
     // children may take go up with the batch, a summary + compact lists come back
     bool fast = false;
+    int tabv = 0;                                // the table version this step's finish writes
+    hipEvent_t scored = nullptr;                 // K4 of the step is queued: the finish (stf) waits for it
     char *d_par = nullptr, *h_par = nullptr;     // [par_d (2 MB f64) | par_i (4 MB i32) | budget (per MB i32)]
     int32_t *c_info = nullptr, *c_cnt = nullptr, *c_eval = nullptr, *c_flag = nullptr;
     double *c_val = nullptr;
@@ -285,9 +287,18 @@ struct mipx_tree {
     // the table block on the device: [cost_l | cost_r | has | pad | times_l | times_r | own sums (4 n)]; with the
     // device finish the device holds the table (every sample reaches it through pc_apply, in stream order) and
     // the host vectors are the snapshot read back with each step
-    size_t tab_off2 = 0, tab_bytes = 0;
-    int32_t *d_times = nullptr;
-    double *d_own = nullptr, *d_primal = nullptr;
+    size_t tab_off2 = 0, tab_bytes = 0, tab_stride = 0;
+    // Device finish: the table is a ring of kTabV versions.  Step k's finish (on stf, beside the node LPs of
+    // step k + 1) copies the version at the tail and applies its samples to the copy; a launch reads the
+    // version of the last step the HOST has finished -- complete by then, never written again while a
+    // kernel in flight reads it, and the same version in every run.
+    int tab_tail = 0, tab_host = 0;
+    hipEvent_t ev_tab = nullptr;     // samples / merges queued on stf behind the last finished step
+    bool tab_pending = false;
+    double *h_delta = nullptr, *d_delta = nullptr;   // exchange: the other ranks' new samples (4 staging slots)
+    int delta_turn = 0;
+    std::vector<double> pc_others_prev;
+    double *d_primal = nullptr;
     double primal_sent = std::numeric_limits<double>::infinity();   // what the device knows of the host's incumbent value
     bool fast_ok = false;           // steps are finished on the device where they file no probe request
     bool times_dirty = false;       // the host replaced the table: times go up with it
@@ -295,6 +306,7 @@ struct mipx_tree {
     std::vector<mipx::PcSample> pend_samples;   // a host-finished step's samples, on their way to the device table
     hipStream_t st2 = nullptr;  // strong-branching probes + re-scoring run beside the step in flight
     hipStream_t st3 = nullptr;  // children records of step k are written beside the node LPs of step k+1
+    hipStream_t stf = nullptr;  // device finish: the finish kernels of step k and the table's version chain, beside the node LPs of step k+1
     hipEvent_t ev_child = nullptr;
     bool child_pending = false;
     int32_t *h_pairs = nullptr; // pinned staging of the branching lists
@@ -437,6 +449,17 @@ void tree_push(mipx_tree *t, int64_t id) {
     }
 }
 
+constexpr int kTabV = 8;   // table versions (device finish): one per step in flight and a few to spare
+struct TabPtr { double *cl, *cr; uint8_t *has; int32_t *times; double *own; };
+TabPtr tab_at(const mipx_tree *t, int v) {
+    char *base = (char *)t->d_cost_l + (size_t)v * t->tab_stride;
+    const size_t n = (size_t)t->n;
+    TabPtr p;
+    p.cl = (double *)base; p.cr = (double *)(base + 8 * n); p.has = (uint8_t *)(base + 16 * n);
+    p.times = (int32_t *)(base + t->tab_off2); p.own = (double *)(base + t->tab_off2 + 8 * n);
+    return p;
+}
+
 // what a launch over nodes with cut rows adds to launch_lp (cut rounds only)
 struct CutLaunch {
     const int32_t *ncut = nullptr, *ids = nullptr;   // the nodes' cut lists, by batch position
@@ -456,7 +479,8 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
     mipx::LpArgs a;
     if (dive) {  // in-place dive: K4's rule inside K1, level p's children at positions p * batch ..
         a.dive = dive->dive; a.dive_off = batch; a.rule = t->rule; a.n_int = t->n_int;
-        a.int_idx = t->d_int_idx; a.cost_l = t->d_cost_l; a.cost_r = t->d_cost_r; a.has_entry = t->d_has;
+        const TabPtr tb = tab_at(t, t->fast_ok ? t->tab_host : 0);
+        a.int_idx = t->d_int_idx; a.cost_l = tb.cl; a.cost_r = tb.cr; a.has_entry = tb.has;
         a.dive_cutoff = t->primal;
         a.dive_var = dive->d_dvar; a.dive_dir = dive->d_ddir; a.dive_val = dive->d_dval;
         a.dive_preset = 1;           // the kernel itself marks "no child / no dive" first
@@ -520,21 +544,23 @@ void layout_pack(mipx_tree *t, StepBuf &S, int levels) {
 }
 
 int launch_score(mipx_tree *t, StepBuf &S, int batch, bool side = false, bool no_ask = false, int side_stream = -1) {
-    const bool on_st2 = side_stream < 0 ? side : side_stream != 0;   // (default: the side tables go with the side stream)
+    const bool on_st2 = side_stream < 0 ? side : side_stream == 1;   // (default: the side tables go with the side stream)
+    hipStream_t where = side_stream == 2 ? t->stf : on_st2 ? t->st2 : t->ctx->stream;   // (2: the finish stream)
     mipx::ScoreArgs s;
     s.n = t->n; s.n_int = t->n_int; s.batch = batch; s.rule = t->rule;
     s.int_idx = t->d_int_idx; s.x = S.d_x; s.status = S.d_status;
-    s.cost_l = side ? t->d_cost_l2 : t->d_cost_l; s.cost_r = side ? t->d_cost_r2 : t->d_cost_r;
-    s.has_entry = side ? t->d_has2 : t->d_has;
+    const TabPtr tb = tab_at(t, t->fast_ok ? t->tab_host : 0);
+    s.cost_l = side ? t->d_cost_l2 : tb.cl; s.cost_r = side ? t->d_cost_r2 : tb.cr;
+    s.has_entry = side ? t->d_has2 : tb.has;
     s.branch_idx = S.d_bidx; s.branch_val = S.d_bval; s.mip_feasible = S.d_mipf;
     s.n_probe = S.d_nprobe;
     s.probe_list = S.d_plist;
     s.ask_count = S.d_ask_count; s.ask_cap = kAskCap; s.ask = (side || no_ask) ? nullptr : S.d_ask;
     s.ask_nodes = S.B;  // dive children (positions >= B) are never probed in their own step
     if (!side && !no_ask && !(S.dive && batch == (S.dive + 1) * S.B && !S.scored_once))
-        HIP_TRY(t->ctx, hipMemsetAsync(S.d_ask_count, 0, 16, t->ctx->stream));
+        HIP_TRY(t->ctx, hipMemsetAsync(S.d_ask_count, 0, 16, side_stream == 2 ? t->stf : t->ctx->stream));
     if (!no_ask) S.scored_once = true;
-    hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, on_st2 ? t->st2 : t->ctx->stream, s);
+    hipLaunchKernelGGL(mipx::branch_score, dim3(batch), dim3(64), 0, where, s);
     HIP_TRY(t->ctx, hipGetLastError());
     return MIPX_OK;
 }
@@ -568,14 +594,19 @@ void pc_update(mipx_tree *t, int var, int dir, int lp_status, double objective, 
 // the kernels that finish a step on the device, queued behind its scoring
 int launch_finish(mipx_tree *t, StepBuf &S) {
     mipx_ctx *ctx = t->ctx;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = t->stf;   // (behind the step's scoring, queued there by tree_launch)
+    const int prev = t->tab_tail;
+    S.tabv = (prev + 1) % kTabV;
+    t->tab_tail = S.tabv;
+    if (t->rule == 1)
+        HIP_TRY(ctx, hipMemcpyAsync(tab_at(t, S.tabv).cl, tab_at(t, prev).cl, t->tab_bytes, hipMemcpyDeviceToDevice, st));
     const int B = S.B, L = t->dive + 1;
     const size_t MB = (size_t)t->max_batch;
     mipx::FinishArgs g;
     g.n = t->n; g.m = t->m; g.B = B; g.dive = S.dive; g.rule = t->rule;
     g.status = S.d_status; g.bidx = S.d_bidx; g.mipf = S.d_mipf; g.nprobe = S.d_nprobe; g.npiv = S.d_npiv;
     g.dvar = S.d_dvar; g.ddir = S.d_ddir; g.obj = S.d_obj; g.bval = S.d_bval; g.dval = S.d_dval;
-    g.ask_count = S.d_ask_count; g.vout = S.d_vout;
+    g.ask_count = S.d_ask_count; g.ask_cap = kAskCap; g.vout = S.d_vout;
     g.slot = S.d_slot;
     g.par_d = (const double *)S.d_par;
     g.par_i = (const int32_t *)(S.d_par + 2 * (size_t)B * 8);
@@ -595,11 +626,34 @@ int launch_finish(mipx_tree *t, StepBuf &S) {
     if (t->rule == 1) {
         hipLaunchKernelGGL(mipx::finish_samples, dim3((B + 255) / 256), dim3(256), 0, st, g);
         mipx::PcApplyArgs a;
+        const TabPtr tb = tab_at(t, S.tabv);
         a.n = t->n; a.sum = S.d_sum; a.count = -1; a.samples = S.d_samples;
-        a.cost_l = t->d_cost_l; a.cost_r = t->d_cost_r; a.has = t->d_has; a.times = t->d_times; a.own = t->d_own;
+        a.cost_l = tb.cl; a.cost_r = tb.cr; a.has = tb.has; a.times = tb.times; a.own = tb.own;
         hipLaunchKernelGGL(mipx::pc_apply, dim3(2 * t->n), dim3(64), 0, st, a);
     }
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(S.done, st));
+    return MIPX_OK;
+}
+
+// The host replaced the table (mipx_tree_set_pseudo_costs): a new version at the tail, read from now on.
+// Rare and blocking: nothing else orders a host-side replacement against the steps in flight.
+int table_replace(mipx_tree *t) {
+    mipx_ctx *ctx = t->ctx;
+    const size_t n = (size_t)t->n;
+    HIP_TRY(ctx, hipStreamSynchronize(t->stf));
+    const int prev = t->tab_tail, w = (prev + 1) % kTabV;
+    const TabPtr src = tab_at(t, prev), dst = tab_at(t, w);
+    HIP_TRY(ctx, hipMemcpy(dst.cl, src.cl, t->tab_bytes, hipMemcpyDeviceToDevice));
+    HIP_TRY(ctx, hipMemcpy(dst.cl, t->cost_l.data(), n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dst.cr, t->cost_r.data(), n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dst.has, t->has_entry.data(), n, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dst.times, t->times_l.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(dst.times + n, t->times_r.data(), n * 4, hipMemcpyHostToDevice));
+    t->tab_tail = w;
+    t->tab_host = w;
+    t->table_dirty = false;
+    t->times_dirty = false;
     return MIPX_OK;
 }
 
@@ -653,6 +707,14 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
     S.in_flight = true;
     t->steps++;
     t->phase_ms[0] += std::chrono::duration<double, std::milli>(now() - tp).count();
+    if (t->fast_ok && t->table_dirty) {
+        const int trc = table_replace(t);
+        if (trc) return trc;
+    }
+    if (t->fast_ok && t->tab_pending) {   // samples of a host-finished step / a merge on their way into the version read below
+        HIP_TRY(ctx, hipStreamWaitEvent(st, t->ev_tab, 0));
+        t->tab_pending = false;
+    }
     if (t->table_dirty) {  // pseudo-cost table as of the last finished step
         const size_t n = t->n;
         // (one copy from the pinned mirror; the previous upload has long been consumed: two steps ago)
@@ -661,19 +723,30 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
         std::memcpy(ht + n * 8, t->cost_r.data(), n * 8);
         std::memcpy(ht + 2 * n * 8, t->has_entry.data(), n);
         HIP_TRY(ctx, hipMemcpyAsync(t->d_cost_l, ht, 17 * n, hipMemcpyHostToDevice, st));
-        if (t->fast_ok && t->times_dirty) {   // (the host replaced the table: an exchange, mipx_tree_set_pseudo_costs)
-            char *tt = t->h_tab + 4 * 17 * n + (size_t)(t->steps & 3) * 8 * n;
-            std::memcpy(tt, t->times_l.data(), n * 4);
-            std::memcpy(tt + n * 4, t->times_r.data(), n * 4);
-            HIP_TRY(ctx, hipMemcpyAsync(t->d_times, tt, 8 * n, hipMemcpyHostToDevice, st));
-            t->times_dirty = false;
-        }
         t->table_dirty = false;
     }
     S.fast = t->fast_ok && !t->trace;
+    if (t->fast_ok && t->rule == 1 && std::getenv("MIPX_DEBUG_TABLE")) {
+        // debugging aid: the version the launch reads against the host's snapshot (equal when nothing is in flight)
+        (void)hipStreamSynchronize(t->stf);
+        std::vector<char> blk(t->tab_bytes);
+        (void)hipMemcpy(blk.data(), tab_at(t, t->tab_host).cl, t->tab_bytes, hipMemcpyDeviceToHost);
+        const size_t n = (size_t)t->n;
+        const double *cl = (const double *)blk.data(), *cr = cl + n;
+        const uint8_t *has = (const uint8_t *)(blk.data() + 16 * n);
+        const int32_t *tl = (const int32_t *)(blk.data() + t->tab_off2), *tr = tl + n;
+        int bad = 0;
+        for (size_t j = 0; j < n; j++)
+            if (cl[j] != t->cost_l[j] || cr[j] != t->cost_r[j] || has[j] != t->has_entry[j] || tl[j] != t->times_l[j] || tr[j] != t->times_r[j]) {
+                if (bad++ < 4)
+                    std::fprintf(stderr, "[mipx table] step %lld var %zu: device (%.17g %.17g has %d times %d %d) host (%.17g %.17g has %d times %d %d)\n",
+                                 (long long)t->steps, j, cl[j], cr[j], has[j], tl[j], tr[j], t->cost_l[j], t->cost_r[j], t->has_entry[j], t->times_l[j], t->times_r[j]);
+            }
+        if (bad) std::fprintf(stderr, "[mipx table] step %lld: %d entries differ (version %d, tail %d)\n", (long long)t->steps, bad, t->tab_host, t->tab_tail);
+    }
     if (S.fast) {
         if (t->primal < t->primal_sent) {   // the host knows a better incumbent than the device (exchange, host-finished step)
-            hipLaunchKernelGGL(mipx::primal_lower, dim3(1), dim3(1), 0, st, t->d_primal, t->primal);
+            hipLaunchKernelGGL(mipx::primal_lower, dim3(1), dim3(1), 0, t->stf, t->d_primal, t->primal);
             t->primal_sent = t->primal;
         }
         // the parents' records and the pool rows the children may take: chain k, level p, direction d owns
@@ -733,8 +806,14 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
                    S.d_x, S.d_vout, S.d_iters, S.d_npiv, nullptr, S.dive ? &S : nullptr, S.d_slot + B);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(S.e1, st));
+    if (S.fast) {
+        // scoring and finish beside the node LPs of the next step: stf waits for this step's node LPs, the main
+        // stream goes straight on to the next launch
+        HIP_TRY(ctx, hipStreamWaitEvent(t->stf, S.e1, 0));
+        if ((rc = launch_score(t, S, (S.dive + 1) * B, false, false, 2))) return rc;
+        return launch_finish(t, S);   // (records S.done behind the finish, on stf)
+    }
     if ((rc = launch_score(t, S, (S.dive + 1) * B))) return rc;
-    if (S.fast && (rc = launch_finish(t, S))) return rc;
     HIP_TRY(ctx, hipEventRecord(S.done, st));
     return MIPX_OK;
 }
@@ -870,9 +949,6 @@ int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
     for (int k = 0; k < B; k++) {
         for (int f = 0; f < 7; f++) t->cut_totals[f] += S.h_cs[4 + (size_t)f * MB + k];
         t->cut_totals[7] += S.h_cs[4 + 8 * MB + k];
-        if (t->trace) {
-            for (int f = 0; f < 8; f++) t->tr_cuts.push_back(S.h_cs[4 + (size_t)f * MB + k]);
-        }
     }
     return MIPX_OK;
 }
@@ -891,12 +967,13 @@ void table_snapshot(mipx_tree *t, const char *blk) {
 
 // Second half of a step the device finished (finish_kernels.hip.h): counters, the new open nodes into the
 // node table and the queue, the free rows back, the incumbent, the table snapshot.
-int tree_finish_fast(mipx_tree *t, StepBuf &S, const mipx::FinishSummary &sum) {
+int tree_finish_fast(mipx_tree *t, StepBuf &S, const mipx::FinishSummary &sum, std::vector<int> &deferred) {
     mipx_ctx *ctx = t->ctx;
     const int B = S.B, n = t->n;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto tp = now();
-    t->lps += B + sum.dives;
+    deferred.clear();
+    t->lps += (B - sum.n_deferred) + sum.dives;
     t->dives += sum.dives;
     t->evaluated += sum.evaluated;
     t->pivots += sum.pivots;
@@ -910,12 +987,24 @@ int tree_finish_fast(mipx_tree *t, StepBuf &S, const mipx::FinishSummary &sum) {
     const bool tab = t->rule == 1;
     mipx::OpenEntry *open = (mipx::OpenEntry *)(hp + (t->tab_bytes + 31) / 32 * 32);
     int32_t *dead = (int32_t *)(open + per * (size_t)t->max_batch);
-    if (tab) HIP_TRY(ctx, hipMemcpyAsync(hp, t->d_cost_l, t->tab_bytes, hipMemcpyDeviceToHost, t->st2));
+    if (tab) HIP_TRY(ctx, hipMemcpyAsync(hp, tab_at(t, S.tabv).cl, t->tab_bytes, hipMemcpyDeviceToHost, t->st2));
+    t->tab_host = S.tabv;   // launches from now on read the table as of this step
     if (sum.n_open > 0)
         HIP_TRY(ctx, hipMemcpyAsync(open, S.d_open, (size_t)sum.n_open * sizeof(mipx::OpenEntry), hipMemcpyDeviceToHost, t->st2));
     if (sum.n_dead > 0)
         HIP_TRY(ctx, hipMemcpyAsync(dead, S.d_dead, (size_t)sum.n_dead * 4, hipMemcpyDeviceToHost, t->st2));
+    if (sum.n_deferred > 0)   // the nodes that filed probe requests: everything the host loop reads per node
+        HIP_TRY(ctx, hipMemcpyAsync(S.h_pack, S.d_pack, S.pack_bytes, hipMemcpyDeviceToHost, t->st2));
     HIP_TRY(ctx, hipStreamSynchronize(t->st2));
+    if (sum.n_deferred > 0) {
+        const int32_t asked = *(const int32_t *)(S.h_pack + S.ask_off);
+        if (asked < 1 || asked > kAskCap) return fail(ctx, MIPX_EHIP, "tree: the device finish deferred nodes without a request list");
+        const mipx::ScoreArgs::Ask *ask = (const mipx::ScoreArgs::Ask *)(S.h_pack + S.ask_off + 16);
+        for (int32_t q = 0; q < asked; q++) deferred.push_back(ask[q].node);
+        std::sort(deferred.begin(), deferred.end());
+        deferred.erase(std::unique(deferred.begin(), deferred.end()), deferred.end());
+        if ((int)deferred.size() != sum.n_deferred) return fail(ctx, MIPX_EHIP, "tree: deferred nodes and request list disagree");
+    }
     t->phase_ms[1] += std::chrono::duration<double, std::milli>(now() - tp).count(); tp = now();
     if (tab) table_snapshot(t, hp);
     // the new open nodes, in the order the host loop created them (chain by chain, level by level, left
@@ -938,7 +1027,15 @@ int tree_finish_fast(mipx_tree *t, StepBuf &S, const mipx::FinishSummary &sum) {
     if (defer_push) t->bq.push_many(t->pend.data(), t->pend.size());
     // rows free again: the budget rows that hold no open node, the batch's own rows
     t->free_slots.insert(t->free_slots.end(), dead, dead + sum.n_dead);
-    t->free_slots.insert(t->free_slots.end(), S.slots.begin(), S.slots.begin() + B);
+    if (deferred.empty()) {
+        t->free_slots.insert(t->free_slots.end(), S.slots.begin(), S.slots.begin() + B);
+    } else {    // (a deferred node's row feeds its children: the host part releases it)
+        size_t d = 0;
+        for (int k = 0; k < B; k++) {
+            if (d < deferred.size() && deferred[d] == k) { d++; continue; }
+            t->free_slots.push_back(S.slots[(size_t)k]);
+        }
+    }
     S.budget.clear();
     t->phase_ms[3] += std::chrono::duration<double, std::milli>(now() - tp).count(); tp = now();
     t->primal_sent = std::fmin(t->primal_sent, sum.primal);
@@ -949,7 +1046,7 @@ int tree_finish_fast(mipx_tree *t, StepBuf &S, const mipx::FinishSummary &sum) {
         t->have_x = true;
     }
     // anchor mode: the root's optimal tableau (a root that needed no probe comes this way)
-    if (t->anchor_mode && !t->anchor_set && S.ids[0] == 0) {
+    if (t->anchor_mode && !t->anchor_set && S.ids[0] == 0 && (deferred.empty() || deferred[0] != 0)) {
         int32_t st0 = -1;
         int rc = tree_d2h(t, &st0, S.d_status, 4);
         if (rc) return rc;
@@ -988,16 +1085,28 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, S.e0, S.e1) == hipSuccess) t->kernel_ms += ms;
     }
+    // The nodes this function finishes, in order.  The whole batch: the nodes without probe requests first,
+    // then those with (each group in batch order) -- the order in which the device finish and the host part
+    // below share a step, so that both ways end with the same table, ids and queue.  Device finish: only
+    // the nodes it deferred (they filed probe requests).
+    std::vector<int> todo;
+    bool partial = false;
     if (S.fast) {
         mipx::FinishSummary *hs = (mipx::FinishSummary *)S.h_fin;
         if ((rc = tree_d2h(t, hs, S.d_sum, sizeof(mipx::FinishSummary)))) return rc;
-        if (!hs->host_path) return tree_finish_fast(t, S, *hs);
-        // probe requests: the host finishes this step; the rows handed out for its children come back
-        t->free_slots.insert(t->free_slots.end(), S.budget.begin(), S.budget.end());
-        S.budget.clear();
+        if (!hs->host_path) {
+            if ((rc = tree_finish_fast(t, S, *hs, todo))) return rc;
+            if (todo.empty()) return MIPX_OK;
+            partial = true;    // (the pack came with the lists)
+        } else {
+            // more probe requests than the compact list holds: the host finishes the whole step; the rows
+            // handed out for its children come back
+            t->free_slots.insert(t->free_slots.end(), S.budget.begin(), S.budget.end());
+            S.budget.clear();
+        }
     }
     // one copy (pinned destination) for everything the host reads per node
-    if ((rc = tree_d2h(t, S.h_pack, S.d_pack, S.pack_bytes))) return rc;
+    if (!partial && (rc = tree_d2h(t, S.h_pack, S.d_pack, S.pack_bytes))) return rc;
     const int L = t->dive + 1;   // (the pack is laid out for the tree's dive depth: layout_pack)
     const size_t MB = (size_t)t->max_batch, OB = (size_t)L * MB, DB = (size_t)(L > 1 ? L - 1 : 1) * MB;
     double *obj = (double *)S.h_pack, *bval = obj + OB, *dval = bval + OB;
@@ -1010,14 +1119,20 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     auto dived = [&](int pos) {
         return pos < S.dive * B && dvar[pos] >= 0 && status[pos + B] >= 0 && nprobe[pos + B] == 0;
     };
-    t->lps += B;
-    for (int k = 0; k < B; k++) t->pivots += npiv[k];
+    if (!partial) {
+        for (int k = 0; k < B; k++)
+            if (nprobe[k] == 0) todo.push_back(k);
+        for (int k = 0; k < B; k++)
+            if (nprobe[k] != 0) todo.push_back(k);
+    }
+    t->lps += (int64_t)todo.size();
+    for (int k : todo) t->pivots += npiv[k];
     t->phase_ms[1] += ms_since(tp); tp = now();
 
     // 3. pseudo costs: strong-branch initialisation + the update for the branch that made the node
     if (t->rule == 1) {
         int64_t total = 0;
-        for (int k = 0; k < B; k++) total += nprobe[k];
+        for (int k : todo) total += nprobe[k];
         std::vector<int32_t> plist, pair_pos, pair_var, pair_slot, child_slot;
         std::vector<double> xrow;  // x of the probed variables
         std::vector<int32_t> pst;
@@ -1112,7 +1227,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         // integer index, left then right), then its own branch unless just initialised
         size_t e = 0;
         bool changed = false;
-        for (int k = 0; k < B; k++) {
+        for (int k : todo) {   // (the requests are sorted by node: the nodes with requests come in that order)
             const bool lp_feasible = status[k] == 0 || status[k] == 2;
             const NodeRec &nd = S.recs[k];
             bool own_probed = false;
@@ -1159,13 +1274,18 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             if (cnt > t->samples_cap) return fail(ctx, MIPX_ENOMEM, "tree: more pseudo-cost samples than the staging holds");
             std::memcpy(S.h_samples, t->pend_samples.data(), cnt * sizeof(mipx::PcSample));
             t->pend_samples.clear();
-            HIP_TRY(ctx, hipMemcpyAsync(S.d_samples, S.h_samples, cnt * sizeof(mipx::PcSample), hipMemcpyHostToDevice, st));
+            // (onto the version at the tail of stf's queue: every later version is copied from it)
+            HIP_TRY(ctx, hipMemcpyAsync(S.d_samples, S.h_samples, cnt * sizeof(mipx::PcSample), hipMemcpyHostToDevice, t->stf));
+            const TabPtr tb = tab_at(t, t->tab_tail);
             mipx::PcApplyArgs pa;
             pa.n = n; pa.sum = nullptr; pa.count = (int)cnt; pa.samples = S.d_samples;
-            pa.cost_l = t->d_cost_l; pa.cost_r = t->d_cost_r; pa.has = t->d_has; pa.times = t->d_times; pa.own = t->d_own;
-            hipLaunchKernelGGL(mipx::pc_apply, dim3(2 * n), dim3(64), 0, st, pa);
+            pa.cost_l = tb.cl; pa.cost_r = tb.cr; pa.has = tb.has; pa.times = tb.times; pa.own = tb.own;
+            hipLaunchKernelGGL(mipx::pc_apply, dim3(2 * n), dim3(64), 0, t->stf, pa);
             HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventRecord(t->ev_tab, t->stf));
+            t->tab_pending = true;
         }
+        if (t->fast_ok) t->tab_host = S.fast ? S.tabv : t->tab_tail;
         if (changed && (!overlapped || total > 0)) {
             // (device finish: the re-scoring reads copies of the host's snapshot + this step's updates, the device
             // table itself only ever changes through pc_apply)
@@ -1178,8 +1298,20 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             if (!side_tab) t->table_dirty = false;
             if ((rc = launch_score(t, S, NB, side_tab, false, use_side ? 1 : 0))) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ps));
-            if ((rc = tree_d2h(t, bidx, S.d_bidx, (size_t)NB * 4))) return rc;
-            if ((rc = tree_d2h(t, bval, S.d_bval, (size_t)NB * 8))) return rc;
+            if (!overlapped) {   // sequential mode: every node branches with the table its step just updated
+                if ((rc = tree_d2h(t, bidx, S.d_bidx, (size_t)NB * 4))) return rc;
+                if ((rc = tree_d2h(t, bval, S.d_bval, (size_t)NB * 8))) return rc;
+            } else {
+                // batches: only the nodes whose probes created the entries their first scoring had to leave out
+                // take the new choice; a node that asked for nothing branches as it was scored at the launch
+                // (what the device finish does with it, before the host ever sees the step)
+                std::vector<int32_t> nb((size_t)B);
+                std::vector<double> nvv((size_t)B);
+                if ((rc = tree_d2h(t, nb.data(), S.d_bidx, (size_t)B * 4))) return rc;
+                if ((rc = tree_d2h(t, nvv.data(), S.d_bval, (size_t)B * 8))) return rc;
+                for (int k : todo)
+                    if (nprobe[k] > 0) { bidx[k] = nb[(size_t)k]; bval[k] = nvv[(size_t)k]; }
+            }
         }
     }
 
@@ -1255,13 +1387,15 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         if (t->trace) {
             t->tr_id.push_back(id); t->tr_status.push_back(status[pos]);
             t->tr_bidx.push_back(branched_on); t->tr_obj.push_back(obj[pos]);
+            if (t->cuts)   // (the node's cut-round counters, in the order of the trace)
+                for (int f = 0; f < 8; f++) t->tr_cuts.push_back(S.h_cs[4 + (size_t)f * MB + pos]);
         }
         return dive_child;
     };
-    for (int k = 0; k < B; k++) {
+    for (int k : todo) {
         int err = MIPX_OK;
         // (a chain reads ten result arrays at every level: more streams than the hardware prefetcher follows)
-        if ((k & 7) == 0 && k + 40 < B) {
+        if (!partial && (k & 7) == 0 && k + 40 < B) {
             for (int lv = 0; lv <= S.dive; lv++) {
                 const int pp = lv * B + k + 32;
                 __builtin_prefetch(&status[pp]); __builtin_prefetch(&obj[pp]); __builtin_prefetch(&mipf[pp]);
@@ -1294,7 +1428,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
     t->phase_ms[3] += ms_since(tp); tp = now();
     // anchor mode: the refactorisations of every later node start from the root's optimal tableau
     // (cut rounds: only a root that kept no cut rows has a basis of the shared rows alone)
-    if (t->anchor_mode && !t->anchor_set && ids[0] == 0 && status[0] == 0 &&
+    if (t->anchor_mode && !t->anchor_set && ids[0] == 0 && status[0] == 0 && (!partial || todo[0] == 0) &&
         !(t->cuts && S.h_cs[4 + 7 * MB] != 0)) {
         std::vector<int8_t> rootv(nv);
         HIP_TRY(ctx, hipMemcpy(rootv.data(), S.d_vout, (size_t)nv, hipMemcpyDeviceToHost));
@@ -1350,7 +1484,7 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         }
     }
     for (int32_t sl : dive_slots) t->free_slots.push_back(sl);
-    for (int k = 0; k < B; k++) t->free_slots.push_back(slots[k]);
+    for (int k : todo) t->free_slots.push_back(slots[k]);
     (void)nv;
     t->phase_ms[4] += ms_since(tp);
     return MIPX_OK;
@@ -1625,6 +1759,43 @@ int x_apply(mipx_tree *t, const char *gathered, bool last) {
             const double *o = rec(r) + kRecHead + n;
             for (size_t j = 0; j < 4 * n; j++) t->pc_others[j] += o[j];
         }
+    }
+    if (t->rule == 1 && t->fast_ok) {
+        // Device finish: the table lives on the device and holds this rank's samples up to the steps in flight.
+        // What the OTHER ranks sampled since the last exchange joins it in sum form (pc_merge, queued on stf
+        // behind the finishes already there); the host's snapshot is merged the same way.
+        if (t->pc_others_prev.size() != 4 * n) t->pc_others_prev.assign(4 * n, 0.0);
+        double *hd = t->h_delta + (size_t)(t->delta_turn & 3) * 4 * n;
+        bool any = false;
+        for (size_t j = 0; j < 4 * n; j++) {
+            hd[j] = t->pc_others[j] - t->pc_others_prev[j];
+            any |= hd[j] != 0.0;
+        }
+        t->pc_others_prev = t->pc_others;
+        if (any) {
+            for (size_t e = 0; e < 2 * n; e++) {
+                const size_t dir = e / n, var = e - dir * n;
+                const double ds = hd[dir * n + var], dt = hd[(2 + dir) * n + var];
+                if (!(dt > 0.0)) continue;
+                double &cost = dir ? t->cost_r[var] : t->cost_l[var];
+                int32_t &times = dir ? t->times_r[var] : t->times_l[var];
+                cost = (cost * (double)times + ds) / ((double)times + dt);
+                times += (int32_t)dt;
+                t->has_entry[var] = 1;
+            }
+            double *dd = t->d_delta + (size_t)(t->delta_turn & 3) * 4 * n;
+            t->delta_turn++;
+            mipx_ctx *ctx = t->ctx;
+            HIP_TRY(ctx, hipMemcpyAsync(dd, hd, 4 * n * 8, hipMemcpyHostToDevice, t->stf));
+            const TabPtr tb = tab_at(t, t->tab_tail);
+            mipx::PcMergeArgs ma;
+            ma.n = t->n; ma.delta = dd; ma.cost_l = tb.cl; ma.cost_r = tb.cr; ma.has = tb.has; ma.times = tb.times;
+            hipLaunchKernelGGL(mipx::pc_merge, dim3((2 * t->n + 255) / 256), dim3(256), 0, t->stf, ma);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventRecord(t->ev_tab, t->stf));
+            t->tab_pending = true;
+        }
+    } else if (t->rule == 1) {
         for (size_t j = 0; j < n; j++) {
             const double tl = t->pc_base[2 * n + j] + t->pc_others[2 * n + j] + t->pc_own[2 * n + j];
             const double tr = t->pc_base[3 * n + j] + t->pc_others[3 * n + j] + t->pc_own[3 * n + j];
@@ -1785,6 +1956,7 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
     int prio_least = 0, prio_greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_greatest = 0;
     if (hipStreamCreateWithPriority(&t->st2, hipStreamNonBlocking, prio_greatest) != hipSuccess) rc |= MIPX_EHIP;
+    if (hipStreamCreateWithPriority(&t->stf, hipStreamNonBlocking, prio_greatest) != hipSuccess) rc |= MIPX_EHIP;
     if (hipStreamCreateWithPriority(&t->st3, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&t->ev_child, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc((void **)&t->h_pairs, 5 * ((size_t)kMaxDive + 1) * B * 4, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
@@ -1828,26 +2000,28 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
         if (hipEventCreate(&S.e0) != hipSuccess || hipEventCreate(&S.e1) != hipSuccess ||
             hipEventCreate(&S.done) != hipSuccess) rc |= MIPX_EHIP;
     }
-    {   // [cost_l | cost_r | has_entry] in one allocation: one upload per step; behind them (device finish)
-        // [times_l | times_r | own sums]
-        char *tab = nullptr;
-        t->tab_off2 = (17 * n + 7) / 8 * 8;
-        t->tab_bytes = t->tab_off2 + 8 * n + 32 * n;
-        rc |= dmalloc(ctx, &tab, t->tab_bytes);
-        t->d_cost_l = (double *)tab;
-        t->d_cost_r = tab ? (double *)(tab + 8 * n) : nullptr;
-        t->d_has = tab ? (uint8_t *)(tab + 16 * n) : nullptr;
-        t->d_times = tab ? (int32_t *)(tab + t->tab_off2) : nullptr;
-        t->d_own = tab ? (double *)(tab + t->tab_off2 + 8 * n) : nullptr;
-        if (hipHostMalloc((void **)&t->h_tab, 4 * 17 * n + 4 * 8 * n, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
-        rc |= dmalloc(ctx, &t->d_primal, 1);
-    }
     // Steps are finished on the device (finish_kernels.hip.h) in the batched modes without cut rounds;
     // MIPX_HOST_FINISH=1 keeps the host loop (A/B runs).  The exact mode (max_batch = 1) reproduces the
     // reference's node order on the host.
     t->fast_ok = max_batch > 1 && !t->cuts && !(std::getenv("MIPX_HOST_FINISH") && std::atoi(std::getenv("MIPX_HOST_FINISH")) != 0);
+    {   // [cost_l | cost_r | has_entry] in one allocation: one upload per step; behind them (device finish)
+        // [times_l | times_r | own sums], and kTabV versions of the whole block
+        char *tab = nullptr;
+        t->tab_off2 = (17 * n + 7) / 8 * 8;
+        t->tab_bytes = t->tab_off2 + 8 * n + 32 * n;
+        t->tab_stride = (t->tab_bytes + 255) / 256 * 256;
+        rc |= dmalloc(ctx, &tab, t->tab_stride * (t->fast_ok ? (size_t)kTabV : 1));
+        t->d_cost_l = (double *)tab;
+        t->d_cost_r = tab ? (double *)(tab + 8 * n) : nullptr;
+        t->d_has = tab ? (uint8_t *)(tab + 16 * n) : nullptr;
+        if (hipHostMalloc((void **)&t->h_tab, 4 * 17 * n + 4 * 8 * n, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
+        rc |= dmalloc(ctx, &t->d_primal, 1);
+    }
     if (t->fast_ok) {
         const size_t per = 2 * LC;
+        rc |= dmalloc(ctx, &t->d_delta, 4 * 4 * n);
+        if (hipHostMalloc((void **)&t->h_delta, 4 * 4 * n * 8, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&t->ev_tab, hipEventDisableTiming) != hipSuccess) rc |= MIPX_EHIP;
         t->samples_cap = (size_t)t->probe_cap + LC * B;
         for (StepBuf &S : t->buf) {
             const size_t par_bytes = 2 * B * 8 + (4 * B + per * B) * 4;
@@ -1858,6 +2032,7 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
             rc |= dmalloc(ctx, &S.d_open, per * B); rc |= dmalloc(ctx, &S.d_dead, per * B);
             rc |= dmalloc(ctx, &S.d_samples, t->samples_cap);
             const size_t fin_bytes = 128 + (t->tab_bytes + 31) / 32 * 32 + per * B * (sizeof(mipx::OpenEntry) + 4);
+            if (hipEventCreateWithFlags(&S.scored, hipEventDisableTiming) != hipSuccess) rc |= MIPX_EHIP;
             if (hipHostMalloc((void **)&S.h_par, par_bytes, hipHostMallocDefault) != hipSuccess ||
                 hipHostMalloc((void **)&S.h_fin, fin_bytes, hipHostMallocDefault) != hipSuccess ||
                 hipHostMalloc((void **)&S.h_samples, t->samples_cap * sizeof(mipx::PcSample), hipHostMallocDefault) != hipSuccess)
@@ -1876,7 +2051,7 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
     t->has_entry.assign(n, 0);
     t->best_x.assign(n, 0.0);
     HIP_TRY(ctx, hipMemcpy(t->d_int_idx, int_idx, (size_t)n_int * 4, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemset(t->d_cost_l, 0, t->tab_bytes));   // costs, entries, times, own sums
+    HIP_TRY(ctx, hipMemset(t->d_cost_l, 0, t->tab_stride * (t->fast_ok ? (size_t)kTabV : 1)));   // costs, entries, times, own sums
     {
         const double inf_ = std::numeric_limits<double>::infinity();
         HIP_TRY(ctx, hipMemcpy(t->d_primal, &inf_, 8, hipMemcpyHostToDevice));
@@ -1914,6 +2089,7 @@ void mipx_tree_destroy(mipx_tree *t) {
     if (t->ctx && t->ctx->stream) (void)hipStreamSynchronize(t->ctx->stream);
     if (t->st2) { (void)hipStreamSynchronize(t->st2); (void)hipStreamDestroy(t->st2); }
     if (t->st3) { (void)hipStreamSynchronize(t->st3); (void)hipStreamDestroy(t->st3); }
+    if (t->stf) { (void)hipStreamSynchronize(t->stf); (void)hipStreamDestroy(t->stf); }
     if (t->ev_child) (void)hipEventDestroy(t->ev_child);
     if (t->h_pairs) (void)hipHostFree(t->h_pairs);
     if (t->h_pres) (void)hipHostFree(t->h_pres);
@@ -1934,10 +2110,14 @@ void mipx_tree_destroy(mipx_tree *t) {
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (t->d_primal) (void)hipFree(t->d_primal);
+    if (t->d_delta) (void)hipFree(t->d_delta);
+    if (t->h_delta) (void)hipHostFree(t->h_delta);
+    if (t->ev_tab) (void)hipEventDestroy(t->ev_tab);
     for (StepBuf &S : t->buf) {
         void *fp[] = {S.d_par, S.c_info, S.c_cnt, S.c_eval, S.c_flag, S.c_val, S.d_sum, S.d_open, S.d_dead, S.d_samples};
         for (void *q : fp)
             if (q) (void)hipFree(q);
+        if (S.scored) (void)hipEventDestroy(S.scored);
         if (S.h_par) (void)hipHostFree(S.h_par);
         if (S.h_fin) (void)hipHostFree(S.h_fin);
         if (S.h_samples) (void)hipHostFree(S.h_samples);
@@ -2096,6 +2276,7 @@ int mipx_tree_solve(mipx_tree *t, int64_t node_limit, double mip_gap, double max
     if (t->x_done) break;
     }
     HIP_TRY(ctx, hipStreamSynchronize(t->st3));
+    HIP_TRY(ctx, hipStreamSynchronize(t->stf));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (t->comm) {
         const int xrc = x_close(t);
@@ -2296,9 +2477,11 @@ int mipx_tree_set_comm(mipx_tree *t, mipx_comm *c, int every_steps) {
         t->pc_base[2 * n + j] = (double)t->times_l[j];
         t->pc_base[3 * n + j] = (double)t->times_r[j];
     }
-    if (t->fast_ok) {   // (nothing is in flight between two solves)
+    if (t->fast_ok) {   // (nothing is in flight between two solves: the tail version is the one every later one copies)
         HIP_TRY(t->ctx, hipStreamSynchronize(t->ctx->stream));
-        HIP_TRY(t->ctx, hipMemset(t->d_own, 0, 4 * n * 8));
+        HIP_TRY(t->ctx, hipStreamSynchronize(t->stf));
+        HIP_TRY(t->ctx, hipMemset(tab_at(t, t->tab_tail).own, 0, 4 * n * 8));
+        t->pc_others_prev.assign(4 * n, 0.0);
     }
     t->g_dual = tree_dual_bound(t);
     for (int k = 0; k < 4; k++) t->g_counts[k] = t->ramp[k];
