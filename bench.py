@@ -63,7 +63,7 @@ def parse_args():
     ap.add_argument('--cpu-seconds', type=float, default=6.0, help='wall seconds of the CPU port baseline (0: skip)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='threads of the CPU baseline; 0 = every CPU this process may use')
     ap.add_argument('--highs-seconds', type=float, default=5.0, help='wall seconds of the HiGHS baseline B2 (0: skip)')
-    ap.add_argument('--tto-seconds', type=float, default=5.0, help='time limit of the time-to-optimal leg (0: skip)')
+    ap.add_argument('--tto-seconds', type=float, default=8.0, help='time limit of the time-to-gap leg on the metric\'s instance (0: skip both time legs)')
     ap.add_argument('--others', type=int, default=1, choices=[0, 1], help='1: also measure C2, C4, C5 (config.others)')
     ap.add_argument('--no-dive-leg', type=int, default=1, choices=[0, 1],
                     help='1: also time the same region with --dive 0 (value_no_dive; one GPU only)')
@@ -300,10 +300,10 @@ def time_to_optimal_leg(args, ctx, A, b, c, l, u, ints):
     """The metric's second leg on its own 256 x 128 instance: the times at which the gap falls below
     1 %, 0.5 %, 0.35 % ... inside the time limit (the tree of this instance does not close at 1e-4 at
     any node rate reached so far: DESIGN.md section 5)."""
-    out = two_phase(ctx, A, b, c, l, u, ints, args.dive, dfs_seconds=0.5 * args.tto_seconds, limit=args.tto_seconds,
-                    pool_log2=23, marks=GAP_MARKS)
+    out = two_phase(ctx, A, b, c, l, u, ints, args.dive, dfs_seconds=0.25 * args.tto_seconds, limit=args.tto_seconds,
+                    pool_log2=24, marks=GAP_MARKS)
     out.update({'instance': f'{len(c)} vars x {len(b)} rows, seed {args.seed} (the metric\'s own instance)',
-                'search': f'two phases in the native engine: depth first (1024 nodes per step) for {0.5 * args.tto_seconds:g} s, then '
+                'search': f'two phases in the native engine: depth first (1024 nodes per step) for {0.25 * args.tto_seconds:g} s, then '
                           f'best first (8192 nodes per step) with the incumbent installed; in-place dive of depth {max(1, args.dive)}',
                 'time_limit_seconds': args.tto_seconds,
                 'note': 'time_to_optimal is null unless the gap closed to 1e-4 inside the time limit; time_to_gap: first time '
@@ -311,7 +311,7 @@ def time_to_optimal_leg(args, ctx, A, b, c, l, u, ints):
     return out
 
 
-def largest_closing_time_to_optimal(ctx, dive, n=128, m=64, limit=60.0):
+def largest_closing_time_to_optimal(ctx, dive, n=144, m=72, limit=60.0):
     """time_to_optimal on the LARGEST instance of the same generator that closes to mip_gap = 1e-4 inside
     the stated limit (a smaller config than the metric's, labelled as such)."""
     from simple_mip_solver_amd.generators import random_dense_milp_arrays
@@ -324,7 +324,7 @@ def largest_closing_time_to_optimal(ctx, dive, n=128, m=64, limit=60.0):
     return out
 
 
-TTO_DFS_SECONDS = 2.0
+TTO_DFS_SECONDS = 1.0
 
 
 def no_dive_leg(args, ctx, prob, l, u, ints, B):
@@ -573,6 +573,7 @@ def main():
             except Exception:
                 traffic = None
         hbm_gbps = None if (traffic is None or stale) else traffic / launch_s / 1e9
+        tree.close()   # (its node pool -- up to 160 GB -- makes room for the legs below)
         nodive = no_dive_leg(args, ctx, prob, l, u, ints, B) if (world == 1 and args.dive and args.no_dive_leg) else None
         tto = time_to_optimal_leg(args, ctx, A, b, c, l, u, ints) if args.tto_seconds > 0 and (n, m) == (256, 128) else None
         tto_small = largest_closing_time_to_optimal(ctx, args.dive) if args.tto_seconds > 0 else None

@@ -15,7 +15,16 @@
 
 namespace mipx {
 
-constexpr int kBigNT = 1024;
+// Threads per workgroup.  One workgroup per CU either way (the LDS borders take ~100 KiB); with 512 threads
+// a lane has 256 registers instead of 128 -- the two rows of 16-byte pairs a wave keeps in flight, the
+// scaled pivot row and the fold arrays fit with 356 B of scratch instead of 816 -- and the kernel is 15 %
+// faster at 1024 x 512 (74.6 -> 85.5 k LP/s; 256 threads: no scratch at all but too few loads in flight,
+// 72.4 k; four rows in flight at 512 threads spill again, 76.2 k).  The arithmetic is per wave and per row:
+// the results do not depend on it.
+#ifndef MIPX_BIG_NT
+#define MIPX_BIG_NT 512
+#endif
+constexpr int kBigNT = MIPX_BIG_NT;
 constexpr int kBigMaxN = 1024;  // 16 elements per lane in the wave folds
 constexpr int kBigMaxM = 1024;
 

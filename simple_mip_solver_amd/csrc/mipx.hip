@@ -38,6 +38,8 @@ struct mipx_problem {
     // K1b (tableau streamed from HBM): one m x n slab per concurrently resident workgroup
     double *big_scratch = nullptr;
     int big_slabs = 0;
+    double *big_scratch2 = nullptr;   // launches beside the main stream's (the engine's probes) stream their own slabs
+    int big_slabs2 = 0;
     // anchor tableau (mipx_problem_set_anchor): warm starts refactor from it
     double *anchor_T = nullptr, *anchor_vec = nullptr;
     int32_t *anchor_idx = nullptr;
@@ -147,19 +149,26 @@ int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t strea
 #endif
     }
     if (!big_fits(p->m, p->n)) return fail(ctx, MIPX_ETOOBIG, "(m,n) exceeds every LP kernel");
-    const int slabs = batch < 1024 ? batch : 1024;  // 1024 x 4 MiB = 4 GiB at 1024 x 512
-    if (slabs > p->big_slabs) {
-        if (p->big_scratch) (void)hipFree(p->big_scratch);
-        p->big_scratch = nullptr;
-        p->big_slabs = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&p->big_scratch, (size_t)slabs * p->m * p->n * sizeof(double)));
-        p->big_slabs = slabs;
+    // one tableau slab per workgroup; a launch on another stream than the context's runs beside the main
+    // one and has slabs of its own (fewer: those launches are the engine's strong-branching probes)
+    const bool side = stream != ctx->stream;
+    const int cap = side ? 256 : 1024;              // 1024 x 4 MiB = 4 GiB at 1024 x 512
+    const int slabs = batch < cap ? batch : cap;
+    double *&scratch = side ? p->big_scratch2 : p->big_scratch;
+    int &have = side ? p->big_slabs2 : p->big_slabs;
+    if (slabs > have) {
+        if (side) HIP_TRY(ctx, hipStreamSynchronize(stream));   // (an earlier side launch may still use the old slabs)
+        if (scratch) (void)hipFree(scratch);
+        scratch = nullptr;
+        have = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&scratch, (size_t)slabs * p->m * p->n * sizeof(double)));
+        have = slabs;
     }
     const size_t lds = mipx::big_lds_bytes(p->m, p->n);
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)mipx::lp_dual_simplex_big,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(mipx::lp_dual_simplex_big, dim3(slabs), dim3(mipx::kBigNT), lds, stream,
-                       a, p->big_scratch);
+                       a, scratch);
     HIP_TRY(ctx, hipGetLastError());
     return MIPX_OK;
 }
@@ -259,6 +268,7 @@ void mipx_problem_destroy(mipx_problem *p) {
     if (p->dbg_vec) (void)hipFree(p->dbg_vec);
     if (p->dbg_idx) (void)hipFree(p->dbg_idx);
     if (p->big_scratch) (void)hipFree(p->big_scratch);
+    if (p->big_scratch2) (void)hipFree(p->big_scratch2);
     if (p->anchor_T) (void)hipFree(p->anchor_T);
     if (p->anchor_vec) (void)hipFree(p->anchor_vec);
     if (p->anchor_idx) (void)hipFree(p->anchor_idx);

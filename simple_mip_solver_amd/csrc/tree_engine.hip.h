@@ -1137,9 +1137,9 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
         std::vector<double> xrow;  // x of the probed variables
         std::vector<int32_t> pst;
         std::vector<double> pobj;
-        // a step in flight on the main stream: probes and re-scoring go to the side stream (K1b
-        // shares one scratch slab per problem, so it stays on the main stream)
-        const bool use_side = overlapped && pick_cfg(t->m, t->n) != nullptr;
+        // a step in flight on the main stream: probes and re-scoring go to the side stream (K1b streams
+        // slabs of its own there)
+        const bool use_side = overlapped;
         hipStream_t ps = use_side ? t->st2 : st;
         if (total > 0) {
             if (2 * total > t->probe_cap) return fail(ctx, MIPX_ENOMEM, "tree: probe pool exhausted");
