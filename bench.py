@@ -391,41 +391,68 @@ def other_configs(args, ctx):
                               'note': 'algorithmic bytes (SURVEY 8d) over the stream time incl. the PCIe copies; the '
                                       'tableau is register-resident, the launch is bound by the 0.6 MB/LP of copies and '
                                       'the dependent pivots of one cold LP'}}
-    # ---- C4: the metric's instance with Gomory cut rounds inside the engine
+    # ---- C4: the metric's instance with Gomory cut rounds inside the engine; C4b: the same shape on a family
+    # where the reference's selection rules DO add cuts below the root (density 0.1), so that cut rows are
+    # carried, re-solved over (K1's cut-row tile) and removed again inside the timed steps
     n, m = 256, 128
-    A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=args.seed)
-    prob = _ffi.Problem(ctx, A, b, c)
-    B4, steps4 = 4096, 10
-    t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=B4, pool_capacity=2 * B4 * (steps4 + 14),
-                  cut_params=dict(max_abs_coef=1000.0 * float(np.max(np.abs(A))), exact_tableau=0))
-    t.set_anchor_mode(True)
-    st = t.stats()
-    while st['open_nodes'] < B4 or st['evaluated_nodes'] == 0:
-        st = t.solve(mip_gap=0.0, frontier_batch=min(B4, 1024), max_steps=1)
-    t.reanchor(st['open_nodes'])   # as C3: the open nodes (none carries a cut row here) get anchors of their own
-    b0, c0 = t.stats(), t.cut_stats()
-    ctx.sync()
-    t0 = time.perf_counter()
-    st = t.solve(mip_gap=0.0, frontier_batch=B4, max_steps=steps4)
-    ctx.sync()
-    el = time.perf_counter() - t0
-    c1 = t.cut_stats()
-    d4 = {k: st[k] - b0[k] for k in ('evaluated_nodes', 'lp_solved', 'probes_solved', 'pivots', 'steps')}
-    out['C4'] = {'workload': f'C3\'s instance with gomory_cuts=True (the reference default): every node runs '
-                             f'BaseNode._base_bound\'s cut loop inside the engine, {B4} nodes per step, best-first, anchored, '
-                             f'no dive', 'kernel': _ffi.kernel_name(m, n) + ' (cut-row variant)',
-                 'nodes_per_s': d4['evaluated_nodes'] / el, 'lps_per_s': d4['lp_solved'] / el,
-                 'ms_per_step': el / max(1, d4['steps']) * 1e3, 'steps': d4['steps'],
-                 'mean_pivots_per_lp': d4['pivots'] / max(1, d4['lp_solved']),
-                 'cut_rounds': c1['total_cut_generation_iterations'] - c0['total_cut_generation_iterations'],
-                 'gmic_created': c1['total_number_gmic_created'] - c0['total_number_gmic_created'],
-                 'gmic_added': c1['total_number_gmic_added'] - c0['total_number_gmic_added'],
-                 'gmic_removed': c1['total_number_gmic_removed'] - c0['total_number_gmic_removed'],
-                 'gmic_dropped_for_capacity': c1['dropped'] - c0['dropped'],
-                 'note': 'on this dense family the reference\'s selection rules reject every rounded GMIC (depth >= 0 '
-                         'after the outer rounding): rounds create cuts, add none, and stall after one round'}
-    t.close()
-    prob.close()
+
+    def cut_config(seed, density, B4, steps4, label):
+        A, b, c, l, u, ints = random_dense_milp_arrays(n, m, density=density, seed=seed)
+        prob = _ffi.Problem(ctx, A, b, c)
+        t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=B4, pool_capacity=2 * B4 * (steps4 + 14),
+                      cut_params=dict(max_abs_coef=1000.0 * float(np.max(np.abs(A))), exact_tableau=0))
+        t.set_anchor_mode(True)
+        st = t.stats()
+        while st['open_nodes'] < B4 or st['evaluated_nodes'] == 0:
+            st = t.solve(mip_gap=0.0, frontier_batch=min(B4, 1024), max_steps=1)
+        t.reanchor(st['open_nodes'])   # as C3: the open nodes that carry no cut row get anchors of their own
+        b0, c0, k0 = t.stats(), t.cut_stats(), t.kernel_ms()
+        ctx.sync()
+        t0 = time.perf_counter()
+        st = t.solve(mip_gap=0.0, frontier_batch=B4, max_steps=steps4)
+        ctx.sync()
+        el = time.perf_counter() - t0
+        c1, k1 = t.cut_stats(), t.kernel_ms()
+        d4 = {k: st[k] - b0[k] for k in ('evaluated_nodes', 'lp_solved', 'probes_solved', 'pivots', 'steps')}
+        created = c1['total_number_gmic_created'] - c0['total_number_gmic_created']
+        k2_s = (k1['gomory'] - k0['gomory']) * 1e-3
+        # K2's slack substitution pi + A' pi_s: one multiply-add per (cut, row, column) -- its GEMM-shaped part
+        k2_flops = 2.0 * m * n * created
+        out = {'workload': label, 'kernel': _ffi.kernel_name(m, n) + ' (cut-row variant)',
+               'nodes_per_s': d4['evaluated_nodes'] / el, 'lps_per_s': d4['lp_solved'] / el,
+               'ms_per_step': el / max(1, d4['steps']) * 1e3, 'steps': d4['steps'],
+               'mean_pivots_per_lp': d4['pivots'] / max(1, d4['lp_solved']),
+               'cut_rounds': c1['total_cut_generation_iterations'] - c0['total_cut_generation_iterations'],
+               'gmic_created': created,
+               'gmic_added': c1['total_number_gmic_added'] - c0['total_number_gmic_added'],
+               'gmic_removed': c1['total_number_gmic_removed'] - c0['total_number_gmic_removed'],
+               'gmic_dropped_for_capacity': c1['dropped'] - c0['dropped'],
+               'kernel_ms_per_step': {'K1_first_solves': (k1['node_lp'] - k0['node_lp']) / max(1, d4['steps']),
+                                      'K2_gomory': (k1['gomory'] - k0['gomory']) / max(1, d4['steps']),
+                                      'pool_append_K3_select': (k1['select'] - k0['select']) / max(1, d4['steps'])},
+               'roofline': {'kernel': 'gomory_cuts<256> (K2)', 'bound': 'mfma',
+                            'achieved': None if k2_s <= 0 else k2_flops / k2_s / 1e12, 'peak': F64_VECTOR_PEAK_TFLOPS,
+                            'unit': 'TFLOP/s', 'frac': None if k2_s <= 0 else k2_flops / k2_s / 1e12 / F64_VECTOR_PEAK_TFLOPS,
+                            'note': 'the multiply-adds of the slack substitution (2 m n per cut created) over K2\'s own time '
+                                    '(HIP events); they run as f64 VALU mul + add in the reference\'s row order -- an MFMA '
+                                    'formulation would change the summation order (DESIGN.md 4b) -- and the kernel is bound '
+                                    'by its instruction stream (profiles/: 5 vector + 3 scalar instructions per multiply-add), '
+                                    'the continued-fraction rounding and three barriers per group of 8 cuts'}}
+        t.close()
+        prob.close()
+        return out
+    out['C4'] = cut_config(args.seed, 1.0, 4096, 10,
+                           'C3\'s instance with gomory_cuts=True (the reference default): every node runs BaseNode._base_bound\'s '
+                           'cut loop inside the engine, 4096 nodes per step, best-first, anchored, no dive')
+    out['C4']['note'] = ('on this dense family the reference\'s selection rules reject every rounded GMIC (depth >= 0 after the '
+                         'outer rounding; tests/golden/base_node_large.npz holds the reference\'s own answer for this root): '
+                         'rounds create cuts, add none, and stall after one round')
+    out['C4b'] = cut_config(1, 0.1, 2048, 6,
+                            'the C4 shape (256 x 128, seed 1) at density 0.1 -- the family of this generator on which the reference\'s '
+                            'rules do add cuts at this size (a sweep over density 1 / 0.5 / 0.25 / 0.1, with and without upper '
+                            'bounds, scripts/c4_tree.py: everywhere else the rounded GMICs are rejected below the root) -- '
+                            'gomory_cuts=True, 2048 nodes per step: nodes carry cut rows (K1\'s <7,7,16,192> tile), gain and lose '
+                            'them in the timed steps')
     # ---- C5 on one GPU: 1024 x 512, the HBM-streaming kernel
     n5, m5, B5, steps5 = 1024, 512, 1024, 5
     A5, b5, c5, l5, u5, ints5 = random_dense_milp_arrays(n5, m5, seed=0)

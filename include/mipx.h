@@ -375,6 +375,10 @@ int mipx_tree_set_trace(mipx_tree *t, int on);
 int64_t mipx_tree_trace(mipx_tree *t, int64_t capacity, int64_t *node_id, int32_t *lp_status,
                         int32_t *branch_var, double *objective);
 
+/* Device time by kernel over the tree's life, HIP events on the stream of the launches (ms): [0] K1 node LPs
+ * (mipx_tree_stats.kernel_ms), [1] K2 gomory_cuts, [2] pool_append + K3 select_cuts, [3] reserved.  [1], [2]:
+ * trees with cut rounds only.  For the roofline entries of bench.py. */
+int mipx_tree_kernel_ms(mipx_tree *t, double out[4]);
 /* Test hooks of the cut rounds (mipx_tree_create_ex with cut parameters).  mipx_tree_trace_cuts: with
  * the trace on, 8 ints per evaluated node in trace order -- cut rounds, iterations / number of GMICs
  * created, added, removed (the per-node increments of BaseNode._base_bound's totals,

@@ -1,4 +1,5 @@
-"""C4 (256 x 128, gomory_cuts=True) on the native frontier engine: nodes/s, LPs/s, GMIC totals."""
+"""C4 (256 x 128, gomory_cuts=True) on the native frontier engine: nodes/s, LPs/s, GMIC totals.
+usage: c4_tree.py [n m B steps exact reanchor seed density unboxed]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
@@ -11,7 +12,11 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 exact = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 ctx = _ffi.Context(0)
-A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=0)
+seed = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+density = float(sys.argv[8]) if len(sys.argv) > 8 else 1.0
+A, b, c, l, u, ints = random_dense_milp_arrays(n, m, density=density, seed=seed)
+if len(sys.argv) > 9 and sys.argv[9] != '0':
+    u = np.full(n, np.inf)
 prob = _ffi.Problem(ctx, A, b, c)
 cp = dict(max_abs_coef=1000.0 * float(np.max(np.abs(A))), exact_tableau=exact)
 t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=B, pool_capacity=2 * B * (steps + 12) + 4 * B,

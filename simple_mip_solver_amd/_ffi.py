@@ -25,7 +25,7 @@ SYMBOLS = [
     'mipx_comm_destroy', 'mipx_comm_rank', 'mipx_comm_size', 'mipx_comm_allgather', 'mipx_comm_barrier',
     'mipx_tree_set_comm', 'mipx_tree_global_stats', 'mipx_exchange_record_len', 'mipx_exchange_decide',
     'mipx_tree_exchange_record', 'mipx_tree_trace_cuts', 'mipx_tree_peek_cuts', 'mipx_tree_cut_store',
-    'mipx_tree_cut_rows_per_node', 'mipx_tree_migrate_self',
+    'mipx_tree_cut_rows_per_node', 'mipx_tree_migrate_self', 'mipx_tree_kernel_ms',
     'mipx_dev_alloc', 'mipx_dev_free',
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
@@ -732,6 +732,14 @@ class Tree:
         L.mipx_tree_global_stats.argtypes = [_vp, C.POINTER(GlobalStats)]
         self.problem.ctx.check(L.mipx_tree_global_stats(self._h, C.byref(st)), 'mipx_tree_global_stats')
         return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def kernel_ms(self):
+        """Device time by kernel (ms): dict(node_lp, gomory, select) (mipx_tree_kernel_ms)."""
+        out = (C.c_double * 4)()
+        L = lib()
+        L.mipx_tree_kernel_ms.argtypes = [_vp, _vp]
+        self.problem.ctx.check(L.mipx_tree_kernel_ms(self._h, out), 'mipx_tree_kernel_ms')
+        return dict(node_lp=out[0], gomory=out[1], select=out[2])
 
     def cut_stats(self):
         """The running GMIC totals of BaseNode._base_bound over every evaluated node (+ 'dropped')."""

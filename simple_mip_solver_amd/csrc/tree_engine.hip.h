@@ -229,6 +229,7 @@ struct StepBuf {
     size_t pack_bytes = 0;
     int32_t *h_slot = nullptr;  // pinned staging of the batch's pool rows
     hipEvent_t e0 = nullptr, e1 = nullptr, done = nullptr;
+    hipEvent_t k2a = nullptr, k2b = nullptr, k3b = nullptr;   // cut rounds: around K2 and K3 of a round
     std::vector<int64_t> ids;
     std::vector<NodeRec> recs;  // the batch's node records, copied at pop time (one random access per node and step)
     std::vector<int32_t> slots;  // staging kept alive
@@ -343,7 +344,7 @@ struct mipx_tree {
     bool have_x = false, unbounded = false, started = false;
     int status = 0;  // 0 unsolved, 1 optimal, 2 infeasible, 3 unbounded, 4 stopped
     int64_t evaluated = 0, lps = 0, probes = 0, pivots = 0, steps = 0, cut_resolves = 0;
-    double solve_seconds = 0.0, kernel_ms = 0.0;
+    double solve_seconds = 0.0, kernel_ms = 0.0, k2_ms = 0.0, k3_ms = 0.0;
     std::vector<double> cost_l, cost_r;
     std::vector<int32_t> times_l, times_r;
     std::vector<uint8_t> has_entry;
@@ -884,8 +885,10 @@ int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
         ga.slab_n = S.cs_state + (size_t)mipx::CF_SLAB_N * B; ga.slab_rows = t->slab_rows;
         ga.group = mipx::gomory_group(n, t->mrows);
         const size_t lds2 = mipx::gomory_lds_bytes(n, t->mrows, ga.group);
+        HIP_TRY(ctx, hipEventRecord(S.k2a, st));
         hipLaunchKernelGGL((mipx::gomory_cuts<256>), dim3(B * ga.chunks), dim3(256), lds2, st, ga);
         HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(S.k2b, st));
         mipx::PoolAppendArgs pa;
         pa.batch = B; pa.slab_rows = t->slab_rows; pa.active = S.cs_active; pa.k2_ncuts = S.k2_ncuts;
         pa.state = S.cs_state; pa.pool_list = S.pool_list;
@@ -901,6 +904,7 @@ int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
         const size_t lds3 = (size_t)t->slab_rows * (3 * 8 + 2 * 4) + 16 + 64;
         hipLaunchKernelGGL(mipx::select_cuts, dim3(B), dim3(256), lds3, st, sa);
         HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(S.k3b, st));
         mipx::CutApplyArgs aa;
         aa.n = n; aa.m0 = t->m; aa.mstride = t->mrows; aa.kc = t->kc; aa.batch = B; aa.slab_rows = t->slab_rows;
         aa.active = S.cs_active; aa.k3_nadded = S.k3_nadded; aa.k3_added = S.k3_added;
@@ -913,6 +917,11 @@ int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipMemcpyAsync(S.h_cs, S.cs_counters, 16, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
+        {   // (the stream is idle: the round's kernel times for the roofline entries of the cut configs)
+            float a = 0.f, b = 0.f;
+            if (hipEventElapsedTime(&a, S.k2a, S.k2b) == hipSuccess) t->k2_ms += a;
+            if (hipEventElapsedTime(&b, S.k2b, S.k3b) == hipSuccess) t->k3_ms += b;   // (pool_append + K3)
+        }
         const int changed = S.h_cs[1];
         maxc = std::max(maxc, (int)S.h_cs[2]);
         if (changed > 0) {   // re-solve where rows came or went, warm from the node's own basis (:319)
@@ -1999,6 +2008,8 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
         rc |= dmalloc(ctx, &S.d_vout, LC * B * nv);
         if (hipEventCreate(&S.e0) != hipSuccess || hipEventCreate(&S.e1) != hipSuccess ||
             hipEventCreate(&S.done) != hipSuccess) rc |= MIPX_EHIP;
+        if (t->cuts && (hipEventCreate(&S.k2a) != hipSuccess || hipEventCreate(&S.k2b) != hipSuccess ||
+                        hipEventCreate(&S.k3b) != hipSuccess)) rc |= MIPX_EHIP;
     }
     // Steps are finished on the device (finish_kernels.hip.h) in the batched modes without cut rounds;
     // MIPX_HOST_FINISH=1 keeps the host loop (A/B runs).  The exact mode (max_batch = 1) reproduces the
@@ -2131,6 +2142,9 @@ void mipx_tree_destroy(mipx_tree *t) {
         if (S.e0) (void)hipEventDestroy(S.e0);
         if (S.e1) (void)hipEventDestroy(S.e1);
         if (S.done) (void)hipEventDestroy(S.done);
+        if (S.k2a) (void)hipEventDestroy(S.k2a);
+        if (S.k2b) (void)hipEventDestroy(S.k2b);
+        if (S.k3b) (void)hipEventDestroy(S.k3b);
     }
     delete t;
 }
@@ -2544,6 +2558,12 @@ int mipx_tree_global_stats(mipx_tree *t, mipx_tree_global_stats_t *out) {
     out->nodes_received = t->nodes_received;
     out->world = t->comm ? t->comm->world : 1;
     out->incumbent_rank = t->comm ? t->g_inc_rank : (t->have_x ? 0 : -1);
+    return MIPX_OK;
+}
+
+int mipx_tree_kernel_ms(mipx_tree *t, double out[4]) {
+    if (!t || !out) return MIPX_EINVAL;
+    out[0] = t->kernel_ms; out[1] = t->k2_ms; out[2] = t->k3_ms; out[3] = 0.0;
     return MIPX_OK;
 }
 
