@@ -7,6 +7,8 @@
 // ~100 KiB at 1024 x 512).  Same arithmetic and reductions as K1; the leaving row is priced with dual
 // Devex weights (w_i from the pivot column alone: the inner products of K1's steepest edge would take
 // another pass over the tableau).  Results are bit-identical to the oracle's for these shapes.
+// Cut rows (LpArgs::ncut, as in K1's CUTS variant): node k has m + ncut[k] rows, the extra ones read from
+// the cut store; slabs, LDS borders and the strided arrays are sized for mstride rows.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -41,46 +43,57 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
     constexpr int NT = kBigNT, NW = NT / 64, CT = 256;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = g.m, n = g.n, nv = n + m;
+    const int m0 = g.m, n = g.n;
+    const bool cuts = g.ncut != nullptr;
+    const int mcap = cuts ? g.mstride : m0;   // rows a node can have: slab, LDS borders and strided arrays are sized for it
     const double INF = __builtin_huge_val();
     int n2 = 64;
     while (n2 < n) n2 <<= 1;
     const int PER = n2 / 64;            // <= 16
-    const int PIr = (m + 63) / 64;      // rows per lane in a wave scan
     // ---- LDS carve ----------------------------------------------------------------------------
     double *s_row = (double *)smem_raw;
     double *s_d = s_row + n, *s_va = s_d + n, *s_vb = s_va + n, *s_lo = s_vb + n, *s_up = s_lo + n;
     double *s_key = s_up + n, *s_aabs = s_key + n, *s_dje = s_aabs + n, *s_x = s_dje + n;
-    double *s_alpha = s_x + n, *s_beta0 = s_alpha + m, *s_ba = s_beta0 + m, *s_bb = s_ba + m;
-    double *s_wgt = s_bb + m;           // dual Devex weights of the rows (reference framework: 1 at the start of a node LP)
-    double *s_cd = s_wgt + m;
+    double *s_alpha = s_x + n, *s_beta0 = s_alpha + mcap, *s_ba = s_beta0 + mcap, *s_bb = s_ba + mcap;
+    double *s_wgt = s_bb + mcap;        // dual Devex weights of the rows (reference framework: 1 at the start of a node LP)
+    double *s_cd = s_wgt + mcap;
     int *s_nvar = (int *)(s_cd + 8), *s_side = s_nvar + n, *s_wlist = s_side + n, *s_bvar = s_wlist + n;
-    int *s_ci = s_bvar + m;             // [0..3] control words, [4] nw
+    int *s_ci = s_bvar + mcap;          // [0..3] control words, [4] nw
     int *s_pos = s_ci + 8;              // column of each variable in the starting tableau, -1 if basic
-    int8_t *s_wantb = (int8_t *)(s_pos + nv), *s_atup = s_wantb + nv, *s_entered = s_atup + nv;
-    double *T = scratch + (size_t)blockIdx.x * (size_t)m * n;
+    int8_t *s_wantb = (int8_t *)(s_pos + (n + mcap)), *s_atup = s_wantb + (n + mcap), *s_entered = s_atup + (n + mcap);
+    double *T = scratch + (size_t)blockIdx.x * (size_t)mcap * n;
 
     for (int node = blockIdx.x; node < g.batch; node += gridDim.x) {
+        if (g.active != nullptr && g.active[node] == 0) continue;   // (uniform over the workgroup)
+        // rows: the m0 shared ones, then this node's cuts (rows of the cut store)
+        const int kcut = cuts ? __builtin_amdgcn_readfirstlane(g.ncut[node]) : 0;
+        const int m = m0 + kcut, nv = n + m;
+        const int32_t *cids = cuts ? g.cut_ids + (size_t)node * g.cut_stride : nullptr;
+        const int PIr = (m + 63) / 64;      // rows per lane in a wave scan
         const size_t src = g.slot ? (size_t)g.slot[node] : (size_t)node;
         const double *gA = g.A + (size_t)node * g.A_stride;
         const double *gb = g.b + (size_t)node * g.b_stride;
         const double *gc = g.c + (size_t)node * g.c_stride;
         const double *lk = g.l + src * n, *uk = g.u + src * n;
-        const int8_t *vin = g.vstat_in ? g.vstat_in + src * nv : nullptr;
+        const int8_t *vin = g.vstat_in ? g.vstat_in + ((cuts && g.vstat_by_node) ? (size_t)node : src) * (size_t)(n + mcap) : nullptr;
         // ---- 0. T = -A, beta0 = -b, d = c, slack basis (or the anchor's tableau state) -------
         // (the anchor may come from the engine's table: entry anchor_sel[node], as in K1)
         const int asel = (g.anchor_sel != nullptr && vin != nullptr) ? __builtin_amdgcn_readfirstlane(g.anchor_sel[node]) : -1;
         const double *aT = asel >= 0 ? g.atab_T + (size_t)asel * ((size_t)m * n) : g.anchor_T;
         const double *avec = asel >= 0 ? g.atab_vec + (size_t)asel * (size_t)(n + 3 * m) : g.anchor_vec;
         const int32_t *aidx = asel >= 0 ? g.atab_idx + (size_t)asel * (size_t)(2 * n + m) : g.anchor_idx;
-        const bool anchored = aT != nullptr && vin != nullptr;
+        const bool anchored = aT != nullptr && vin != nullptr && kcut == 0;   // (an anchor has the shared rows only)
         if (anchored) {
             for (size_t e = tid; e < (size_t)m * n; e += NT) T[e] = aT[e];
         } else {
-            for (size_t e = tid; e < (size_t)m * n; e += NT) T[e] = -gA[e];
+            for (size_t e = tid; e < (size_t)m0 * n; e += NT) T[e] = -gA[e];
+            for (int i = m0; i < m; i++) {
+                const double *cp = g.cut_pi + (size_t)cids[i - m0] * n;
+                for (int j = tid; j < n; j += NT) T[(size_t)i * n + j] = -cp[j];
+            }
         }
         for (int i = tid; i < m; i += NT) {
-            s_beta0[i] = anchored ? avec[n + i] : -gb[i];
+            s_beta0[i] = anchored ? avec[n + i] : (i < m0 ? -gb[i] : -g.cut_pi0[cids[i - m0]]);
             s_bvar[i] = anchored ? aidx[n + i] : n + i;
             s_ba[i] = 0.0; s_bb[i] = 0.0; s_entered[i] = 0;
         }
@@ -452,21 +465,21 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
         __syncthreads();
         if (g.x) for (int j = tid; j < n; j += NT) g.x[onode * n + j] = s_x[j];
         if (g.y) {
-            for (int i = tid; i < m; i += NT) g.y[onode * m + i] = 0.0;
+            for (int i = tid; i < m; i += NT) g.y[onode * mcap + i] = 0.0;
             __syncthreads();
             for (int j = tid; j < n; j += NT)
-                if (s_nvar[j] >= n) g.y[onode * m + (s_nvar[j] - n)] = s_d[j];
+                if (s_nvar[j] >= n) g.y[onode * mcap + (s_nvar[j] - n)] = s_d[j];
         }
         if (g.vstat_out) {
-            int8_t *vo = g.vstat_out + onode * nv;
+            int8_t *vo = g.vstat_out + onode * (size_t)(n + mcap);
             for (int i = tid; i < m; i += NT) vo[s_bvar[i]] = 1;
             for (int j = tid; j < n; j += NT) vo[s_nvar[j]] = s_side[j] ? 2 : 3;
         }
         if (g.dbg_T && (node == 0 || g.dbg_all)) {
             const size_t k = g.dbg_all ? (size_t)node : 0;
-            double *dT = g.dbg_T + k * (size_t)m * n;
-            double *dvec = g.dbg_vec + k * (size_t)(n + 3 * m);
-            int32_t *didx = g.dbg_idx + k * (size_t)(2 * n + m);
+            double *dT = g.dbg_T + k * (size_t)mcap * n;
+            double *dvec = g.dbg_vec + k * (size_t)(n + 3 * mcap);
+            int32_t *didx = g.dbg_idx + k * (size_t)(2 * n + mcap);
             for (size_t e = tid; e < (size_t)m * n; e += NT) dT[e] = T[e];
             for (int j = tid; j < n; j += NT) { dvec[j] = s_d[j]; didx[j] = s_nvar[j]; didx[n + m + j] = s_side[j]; }
             for (int i = tid; i < m; i += NT) {

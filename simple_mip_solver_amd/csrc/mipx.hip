@@ -40,6 +40,7 @@ struct mipx_problem {
     int big_slabs = 0;
     double *big_scratch2 = nullptr;   // launches beside the main stream's (the engine's probes) stream their own slabs
     int big_slabs2 = 0;
+    int big_rows = 0;                 // rows per slab (m, or m + cut rows once a launch carried them)
     // anchor tableau (mipx_problem_set_anchor): warm starts refactor from it
     double *anchor_T = nullptr, *anchor_vec = nullptr;
     int32_t *anchor_idx = nullptr;
@@ -108,8 +109,7 @@ int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t strea
     mipx_ctx *ctx = p->ctx;
     if (!stream) stream = ctx->stream;
     if (m_rows < 0) m_rows = p->m;
-    if (a.ncut && !pick_cfg(m_rows, p->n))
-        return fail(ctx, MIPX_ETOOBIG, "cut rows are only supported on the register-tile kernels");
+    // (a launch with cut rows above the register tiles goes to K1b like any other shape above them)
     if (const KernelCfg *cfg = pick_cfg(m_rows, p->n)) {
 #ifdef MIPX_KPROF
         // profiling build: per-section cycle totals of wave 0, summed over the launch
@@ -148,7 +148,9 @@ int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t strea
         return MIPX_OK;
 #endif
     }
-    if (!big_fits(p->m, p->n)) return fail(ctx, MIPX_ETOOBIG, "(m,n) exceeds every LP kernel");
+    // rows a node can have: the shared ones, or (cut rows) the rows allotted per node
+    const int mcap = a.ncut ? a.mstride : p->m;
+    if (mcap < m_rows || !big_fits(mcap, p->n)) return fail(ctx, MIPX_ETOOBIG, "(m,n) exceeds every LP kernel");
     // one tableau slab per workgroup; a launch on another stream than the context's runs beside the main
     // one and has slabs of its own (fewer: those launches are the engine's strong-branching probes)
     const bool side = stream != ctx->stream;
@@ -156,15 +158,20 @@ int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t strea
     const int slabs = batch < cap ? batch : cap;
     double *&scratch = side ? p->big_scratch2 : p->big_scratch;
     int &have = side ? p->big_slabs2 : p->big_slabs;
+    if (mcap > p->big_rows) {   // (slabs of mcap rows: what is there is too small)
+        have = 0;
+        if (!side) p->big_slabs2 = 0; else p->big_slabs = 0;
+        p->big_rows = mcap;
+    }
     if (slabs > have) {
         if (side) HIP_TRY(ctx, hipStreamSynchronize(stream));   // (an earlier side launch may still use the old slabs)
         if (scratch) (void)hipFree(scratch);
         scratch = nullptr;
         have = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&scratch, (size_t)slabs * p->m * p->n * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void **)&scratch, (size_t)slabs * p->big_rows * p->n * sizeof(double)));
         have = slabs;
     }
-    const size_t lds = mipx::big_lds_bytes(p->m, p->n);
+    const size_t lds = mipx::big_lds_bytes(mcap, p->n);
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)mipx::lp_dual_simplex_big,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(mipx::lp_dual_simplex_big, dim3(slabs), dim3(mipx::kBigNT), lds, stream,
@@ -365,7 +372,10 @@ int mipx_lp_solve_batch_cuts(mipx_problem *p, int batch, const double *l, const 
                 return fail(ctx, MIPX_EINVAL, "mipx_lp_solve_batch_cuts: cut id out of range");
         if (ncut[k] > maxc) maxc = ncut[k];
     }
-    if (!pick_cfg(p->m + maxc, p->n)) return fail(ctx, MIPX_ETOOBIG, "mipx_lp_solve_batch_cuts: m + cuts exceeds the register tiles");
+    // (a problem of the register tiles stays on them with its cut rows -- one pricing rule for all its LPs --
+    // or is refused; above the tiles the streamed kernel takes the cut rows too)
+    if (pick_cfg(p->m, p->n) ? !pick_cfg(p->m + maxc, p->n) : !big_fits(p->m + kc, p->n))
+        return fail(ctx, MIPX_ETOOBIG, "mipx_lp_solve_batch_cuts: m + cuts exceeds the LP kernels of this shape");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t B = (size_t)batch, n = (size_t)p->n, M = (size_t)p->m + kc, nvs = n + M, NC = (size_t)(ncuts_total ? ncuts_total : 1);
     size_t off = 0;

@@ -1913,11 +1913,17 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
             !(cuts->cutting_plane_progress_tolerance > 0) || !(cuts->min_cut_depth > 0) || !(cuts->max_term > 0) ||
             cuts->store_capacity < 0)
             return fail(ctx, MIPX_EINVAL, "mipx_tree_create_ex: bad cut parameter");
-        // the rows of a node must fit a register tile; keep as many cut rows as the largest tile takes
-        while (kc > 0 && pick_cfg(p->m + kc, p->n) == nullptr) kc--;
+        if (pick_cfg(p->m, p->n) != nullptr) {
+            // register tiles: the rows of a node must fit one; keep as many cut rows as the largest tile takes
+            // (all launches of the tree then price alike: the tiles' steepest edge)
+            while (kc > 0 && pick_cfg(p->m + kc, p->n) == nullptr) kc--;
+        } else {
+            // above them every launch streams its tableau (K1b): the slabs take the cut rows too
+            while (kc > 0 && !big_fits(p->m + kc, p->n)) kc--;
+        }
         if (kc == 0)
-            return fail(ctx, MIPX_ETOOBIG, "mipx_tree_create_ex: cut rounds need m + cuts <= 192 rows, n <= 256 "
-                                            "(the register-tile kernels)");
+            return fail(ctx, MIPX_ETOOBIG, "mipx_tree_create_ex: no room for a cut row (m + cuts <= 192 rows on the register "
+                                            "tiles, <= 1024 above them)");
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     mipx_tree *t = new (std::nothrow) mipx_tree();

@@ -39,7 +39,8 @@ def hip_backend():
 
 
 # ---- (1) the kernel variant -----------------------------------------------------------------------
-@pytest.mark.parametrize('n,m,seed', [(12, 6, 0), (64, 32, 1), (100, 40, 2), (256, 128, 0), (200, 150, 3)])
+@pytest.mark.parametrize('n,m,seed', [(12, 6, 0), (64, 32, 1), (100, 40, 2), (256, 128, 0), (200, 150, 3),
+                                       (300, 150, 0), (600, 300, 2)])   # (the last two: K1b, tableau streamed)
 def test_lp_with_cut_rows_matches_the_oracle_on_materialised_rows(n, m, seed, gpu_ctx, oracle):
     A, b, c, l, u, ints = random_dense_milp_arrays(n, m, seed=seed)
     p = _ffi.Problem(gpu_ctx, A, b, c)
@@ -51,7 +52,7 @@ def test_lp_with_cut_rows_matches_the_oracle_on_materialised_rows(n, m, seed, gp
     store_pi = np.vstack([g['pi'], g['safe_pi']])
     store_pi0 = np.concatenate([g['pi0'], g['safe_pi0']])
     K = len(store_pi0)
-    kc = min(64, 192 - m) if m + 64 > 128 else 64
+    kc = 64 if n > 256 else (min(64, 192 - m) if m + 64 > 128 else 64)   # (above the register tiles: K1b takes 64)
     rng = np.random.default_rng(seed)
     sizes = [0, 1, 2, min(5, K), min(kc, K), min(kc // 2, K), 0, 3]
     lists = [sorted(rng.choice(K, size=s, replace=False).tolist()) if s else [] for s in sizes]
@@ -92,10 +93,14 @@ def test_cut_row_entry_point_checks_its_arguments(gpu_ctx):
     pi = np.ones((2, 12)); pi0 = np.zeros(2)
     with pytest.raises(_ffi.MipxError, match='cut id out of range'):
         p.solve_batch_cuts(l[None], u[None], None, pi, pi0, [[0, 5]])
-    A2, b2, c2, l2, u2, _ = random_dense_milp_arrays(256, 150, seed=0)
+    A2, b2, c2, l2, u2, _ = random_dense_milp_arrays(256, 150, seed=0)   # a register-tile shape whose cut rows leave the tiles
     p2 = _ffi.Problem(gpu_ctx, A2, b2, c2)
     with pytest.raises(_ffi.MipxError, match='MIPX_ETOOBIG'):
         p2.solve_batch_cuts(l2[None], u2[None], None, np.ones((64, 256)), np.zeros(64), [list(range(64))])
+    A3, b3, c3, l3, u3, _ = random_dense_milp_arrays(600, 1000, seed=0)  # 1000 + 64 rows: above every kernel
+    p3 = _ffi.Problem(gpu_ctx, A3, b3, c3)
+    with pytest.raises(_ffi.MipxError, match='MIPX_ETOOBIG'):
+        p3.solve_batch_cuts(l3[None], u3[None], None, np.ones((64, 600)), np.zeros(64), [list(range(64))])
 
 
 # ---- (2) the engine against the per-node Python path -------------------------------------------------
@@ -331,10 +336,11 @@ def test_example_models_batched_with_cuts():
 def test_cut_mode_limits():
     with pytest.raises(AssertionError, match='dive is not available'):
         BranchAndBound(random_model(20, 10, 1), frontier_batch=8, dive=True)
-    # shapes beyond the register tiles have no cut-row kernel
-    bb = BranchAndBound(random_model(300, 150, 0), PseudoCostBranchNode, pseudo_costs={}, frontier_batch=4)
-    with pytest.raises(_ffi.MipxError, match='MIPX_ETOOBIG'):
-        bb.solve()
+    # shapes beyond the register tiles run their cut rounds on the HBM-streaming kernel (reference default
+    # gomory_cuts=True at BASELINE config C5's kind of shape)
+    bb = BranchAndBound(random_model(300, 150, 0), PseudoCostBranchNode, pseudo_costs={}, frontier_batch=4, node_limit=24)
+    bb.solve()
+    assert bb._native.cuts and bb._kwargs['total_cut_generation_iterations'] > 0 and bb._kwargs['total_number_gmic_created'] > 0
 
 
 # ---- (4) one step of the BATCHED cut mode, node by node through the oracle ---------------------------
@@ -421,7 +427,8 @@ def replay_cut_loop(oracle, A, b, c, l, u, ints, first, rows_pi, rows_pi0, vstat
     (256, 128, 0, 1.0, True, 400, 1024),     # BASELINE C4: the bench's family (cuts created, none added)
     (256, 128, 1, 1.0, False, 200, 512),     # 256 x 128 where the reference's rules DO add cuts: nodes carry rows
     (64, 32, 5, 1.0, False, 200, 512),       # nodes that carry, gain and lose cut rows
-    (64, 32, 2, 0.25, True, 200, 512)])
+    (64, 32, 2, 0.25, True, 200, 512),
+    (300, 30, 5, 1.0, False, 60, 128)])      # above the register tiles (n > 256): K1b with cut rows carried, gained and lost
 def test_batched_cut_mode_step_replays_through_the_oracle(n, m, seed, density, boxed, target, MB, exact, gpu_ctx, oracle):
     """The configuration bench.py measures C4 on -- exact_tableau=0 (K2 reads the tableau a solve ends
     with), anchored, re-anchored, a whole frontier per step -- checked at step level: every node of one
