@@ -330,11 +330,11 @@ TTO_DFS_SECONDS = 1.0
 def no_dive_leg(args, ctx, prob, l, u, ints, B):
     """The same timed region WITHOUT the plunge (--dive 0): pure best first as north_star states it --
     every LP of a step is one of the B best open nodes.  Same instance, ramp-up, re-anchoring and timing
-    brackets; fewer steps."""
+    brackets and number of steps."""
     from simple_mip_solver_amd import _ffi
-    steps = max(10, args.steps // 4)
+    steps = max(10, args.steps)
     n, m = prob.n, prob.m
-    pool = min(2 * B * (steps + 3 + 8) + 4 * B, int(40e9 // (2 * 8 * n + n + m)))
+    pool = min(2 * B * (steps + max(3, args.warmup) + 8) + 4 * B, int(40e9 // (2 * 8 * n + n + m)))
     t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', search_rule='best first', strong_branch_iters=5,
                   max_batch=B, pool_capacity=pool)
     if not args.no_anchor:
@@ -344,7 +344,7 @@ def no_dive_leg(args, ctx, prob, l, u, ints, B):
         st = t.solve(mip_gap=0.0, frontier_batch=min(B, 1024), max_steps=1)
     if args.reanchor and not args.no_anchor:
         t.reanchor(t.stats()['open_nodes'])
-    t.solve(mip_gap=0.0, frontier_batch=B, max_steps=3)
+    t.solve(mip_gap=0.0, frontier_batch=B, max_steps=max(3, args.warmup))
     b0 = t.stats()
     ctx.sync()
     t0 = time.perf_counter()
@@ -396,7 +396,7 @@ def other_configs(args, ctx):
     # carried, re-solved over (K1's cut-row tile) and removed again inside the timed steps
     n, m = 256, 128
 
-    def cut_config(seed, density, B4, steps4, label):
+    def cut_config(seed, density, B4, steps4, label, n=256, m=128):
         A, b, c, l, u, ints = random_dense_milp_arrays(n, m, density=density, seed=seed)
         prob = _ffi.Problem(ctx, A, b, c)
         t = _ffi.Tree(prob, ints, l, u, branch_rule='pseudo cost', max_batch=B4, pool_capacity=2 * B4 * (steps4 + 14),
@@ -453,6 +453,10 @@ def other_configs(args, ctx):
                             'bounds, scripts/c4_tree.py: everywhere else the rounded GMICs are rejected below the root) -- '
                             'gomory_cuts=True, 2048 nodes per step: nodes carry cut rows (K1\'s <7,7,16,192> tile), gain and lose '
                             'them in the timed steps')
+    out['C5_cuts_single_gpu'] = cut_config(0, 1.0, 256, 3,
+                                           'C5\'s instance (1024 x 512, seed 0) with the reference\'s default gomory_cuts=True: cut rounds '
+                                           'inside the engine on the HBM-streaming kernel (K1b with per-node cut rows), 256 nodes per step, '
+                                           'no dive (one GPU of the 8 the config names)', n=1024, m=512)
     # ---- C5 on one GPU: 1024 x 512, the HBM-streaming kernel
     n5, m5, B5, steps5 = 1024, 512, 1024, 5
     A5, b5, c5, l5, u5, ints5 = random_dense_milp_arrays(n5, m5, seed=0)
