@@ -91,11 +91,13 @@ if fe and wr:
     for r in csv.DictReader(open(O + f'/{TAG}_k1b_kernel_by_grid.csv')):
         if 'lp_dual_simplex_big' in r['kernel'] and int(r['grid_x']) == g:
             dur = float(r['avg_us'])
-    k1b = {"command": "rocprofv3 (trace / --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes) -- python3 scripts/c5_tree.py 1024 8",
+    k1b = {"command": "rocprofv3 (trace / --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes) -- python3 scripts/c5_tree.py 1024 8 1",
            "kernel": f"lp_dual_simplex_big (K1b) at 1024 x 512, grid {g} threads (1024 nodes + their plunge of depth 8 per launch)",
            "fetch_size_KB_raw": f_kb, "write_size_KB": w_kb, "hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024,
            "avg_launch_us": dur,
            "hbm_GBps": None if not dur else (2 * f_kb + w_kb) * 1024 / (dur * 1e-6) / 1e9}
     json.dump(k1b, open(O + f'/{TAG}_k1b_pmc.json', 'w'), indent=1)
     print(json.dumps(k1b))
+if glob.glob(O + '/c4_trace/*/*kernel_trace.csv'):
+    by_grid(O + '/c4_trace', O + f'/{TAG}_c4_kernel_by_grid.csv')
 print(open(O + f'/{TAG}_kernel_by_grid.csv').read()[:3000])

@@ -22,8 +22,11 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE --output-format csv -d $O/sq2 -- python3 $R/bench.py $ARGS > $O/sq2.log 2>&1 || echo "sq2 failed"
 echo sq done
 # K1b on C5 (1024 x 512): trace + HBM bytes
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/k1b_trace -- python3 $R/scripts/c5_tree.py 1024 8 > $O/k1b_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/k1b_fetch -- python3 $R/scripts/c5_tree.py 1024 8 > $O/k1b_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/k1b_write -- python3 $R/scripts/c5_tree.py 1024 8 > $O/k1b_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/k1b_trace -- python3 $R/scripts/c5_tree.py 1024 8 1 > $O/k1b_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/k1b_fetch -- python3 $R/scripts/c5_tree.py 1024 8 1 > $O/k1b_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/k1b_write -- python3 $R/scripts/c5_tree.py 1024 8 1 > $O/k1b_write.log 2>&1
 echo k1b done
+# C4 (cut rounds in the engine): kernel trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_trace -- python3 $R/scripts/c4_tree.py 256 128 4096 10 > $O/c4_trace.log 2>&1
+echo c4 done
 python3 $R/scripts/collect_profiles.py $O
