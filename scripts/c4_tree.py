@@ -2,7 +2,7 @@
 usage: c4_tree.py [n m B steps exact reanchor seed density unboxed]"""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from math import cos, radians
 from simple_mip_solver_amd import _ffi
 from simple_mip_solver_amd.generators import random_dense_milp_arrays

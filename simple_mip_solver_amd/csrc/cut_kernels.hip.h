@@ -227,6 +227,11 @@ struct GomoryArgs {
     double *safe_pi, *safe_pi0;   // rounded ('over' coefficients, 'under' right-hand side)
     int chunks = 1;               // workgroups per node: cut c of a node is worked out by workgroup c % chunks
     int group = 1;                // cuts a workgroup substitutes the slacks of at once (<= kGomoryGroup; LDS: gomory_lds_bytes)
+    // EXPERIMENT (MIPX_K2_MFMA=1, never the default): the slack substitution pi + A' pi_s of a group as
+    // v_mfma_f64_16x16x4_f64 tiles (cuts x columns, reduced over rows four at a time, fused) instead of the
+    // reference's row-by-row multiply-then-add.  Another summation order: the raw coefficients differ in
+    // their last bits from the canonical ones (tests/test_cut_kernels_gpu.py reports by how much).
+    int mfma = 0;
     // ---- frontier engine with cut rounds (all optional) ------------------------------------------
     // per-node cut rows, as in LpArgs: node k has m + ncut[k] rows, row m + i = cut cut_ids[k * cut_stride + i]
     const int32_t *ncut = nullptr, *cut_ids = nullptr;
@@ -370,6 +375,34 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
             }
         }
         __syncthreads();
+        if (g.mfma) {
+            // one 16 x 16 tile = 16 cuts (the group's, zero-padded) x 16 columns per wave and step of four rows:
+            // A operand ps[cut = lane & 15][row = 4 kb + (lane >> 4)] from LDS, B operand A[row][col0 + (lane & 15)]
+            // from L2, D: column lane & 15, cuts (lane >> 4) + 4 r
+            typedef double d4v __attribute__((ext_vector_type(4)));
+            const int cq_ = lane & 15, kq_ = lane >> 4;
+            for (int tile = wave; tile * 16 < n; tile += NT / 64) {
+                const int var = tile * 16 + cq_;
+                d4v acc = {0.0, 0.0, 0.0, 0.0};
+                for (int i0 = 0; i0 < m; i0 += 4) {
+                    const int i = i0 + kq_;
+                    const double a_op = (cq_ < gc && i < m) ? pi_var[(size_t)cq_ * (n + ms) + n + i] : 0.0;
+                    double b_op = 0.0;
+                    if (i < m && var < n) b_op = i < m0 ? g.A[(size_t)i * n + var] : g.cut_pi[(size_t)cids[i - m0] * n + var];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int q = kq_ + 4 * r;
+                    if (q < gc && var < n) {
+                        double *pv = pi_var + (size_t)q * (n + ms);
+                        const double coef = pv[var] + acc[r];
+                        if (g.pi) g.pi[((size_t)node * ms + (c0 + q * g.chunks)) * n + var] = coef;
+                        pv[var] = coef;
+                    }
+                }
+            }
+        } else
         // coefs = pi + A' ps, accumulated row by row (the order of the reference's sparse product);
         // the node's cut rows follow the shared ones
         for (int var = tid; var < n; var += NT) {

@@ -412,15 +412,16 @@ __global__ __launch_bounds__(64) void pc_apply(PcApplyArgs a) {
     int times = a.times[dir * n + var];
     double own_sum = a.own[dir * n + var], own_t = a.own[(2 + dir) * n + var];
     bool any = false;
-    for (int base0 = 0; base0 < cnt; base0 += 256) {
-        int key[4];
+    constexpr int UN = 16;   // loads in flight per lane: the walk is bound by their latency
+    for (int base0 = 0; base0 < cnt; base0 += 64 * UN) {
+        int key[UN];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {   // four loads in flight per lane: the walk is bound by their latency
+        for (int c = 0; c < UN; c++) {
             const int i = base0 + 64 * c + lane;
             key[c] = i < cnt ? a.samples[i].var_dir : -1;
         }
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int c = 0; c < UN; c++) {
             const int base = base0 + 64 * c;
             unsigned long long mask = __ballot(key[c] == vd);
             while (mask) {

@@ -135,3 +135,42 @@ def test_select_cuts_on_generated_pools(gpu_ctx, oracle):
         ga, gt, gd = _ffi.select_cuts(gpu_ctx, *args)
         oa, ot, od = oracle.select_cuts(*args)
         assert np.array_equal(ga, oa) and gt == ot and np.array_equal(gd, od), trial
+
+
+def test_mfma_substitution_experiment_distance_from_the_canonical_order(gpu_ctx, capsys):
+    """MIPX_K2_MFMA=1 (an experiment, never the default): K2's slack substitution pi + A' pi_s as
+    v_mfma_f64_16x16x4_f64 tiles -- rows reduced four at a time, fused -- instead of the reference's
+    row-by-row multiply-then-add.  Not asserted equal: MEASURED.  On the reference-generated 64 x 32 and
+    256 x 128 nodes (tests/golden/base_node_large.npz) the rows are the same, the raw coefficients move by
+    a few ulp of the cut's largest coefficient, and the safely rounded cuts -- what the selection sees --
+    almost never change (the continued-fraction rounding absorbs last-bit noise except at knife edges)."""
+    import os
+    Z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'base_node_large.npz'))
+    worst, coefs, moved_raw, moved_rounded, cuts = 0.0, 0, 0, 0, 0
+    for ci, (n, m, seed, density, boxed) in enumerate(Z['cases']):
+        A, b, c, _, _, ints = random_dense_milp_arrays(int(n), int(m), density=float(density), seed=int(seed))
+        p = _ffi.Problem(gpu_ctx, A, b, c)
+        keys = [f'c{ci}_k{k}_' for k in range(int(Z[f'c{ci}_count'][0]))]
+        args = (np.stack([Z[q + 'l'] for q in keys]), np.stack([Z[q + 'u'] for q in keys]),
+                np.stack([Z[q + 'vstat'] for q in keys]), np.stack([Z[q + 'x'] for q in keys]), ints)
+        canon = p.gomory_batch(*args)
+        os.environ['MIPX_K2_MFMA'] = '1'
+        try:
+            fused = p.gomory_batch(*args)
+        finally:
+            os.environ.pop('MIPX_K2_MFMA', None)
+        for a, f in zip(canon, fused):
+            assert np.array_equal(a['row_idx'], f['row_idx']) and np.array_equal(a['pi0'], f['pi0'])
+            scale = np.max(np.abs(a['pi']), axis=1, keepdims=True)
+            worst = max(worst, float(np.max(np.abs(a['pi'] - f['pi']) / scale)))
+            coefs += a['pi'].size
+            cuts += len(a['pi'])
+            moved_raw += int(np.sum(a['pi'] != f['pi']))
+            moved_rounded += int(np.sum(a['safe_pi'] != f['safe_pi']))
+        p.close()
+    with capsys.disabled():
+        print(f'\n[K2 MFMA experiment] {cuts} cuts, {coefs} coefficients: {moved_raw} raw coefficients differ, largest '
+              f'difference {worst:.2e} of the cut\'s largest coefficient ({worst / 2.2e-16:.1f} ulp); '
+              f'{moved_rounded} rounded coefficients differ')
+    assert 0 < moved_raw and worst < 1e-13          # another summation order: last bits only
+    assert moved_rounded <= coefs // 500            # ... which the safe rounding almost always absorbs
