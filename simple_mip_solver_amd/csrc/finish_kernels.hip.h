@@ -89,6 +89,7 @@ struct FinishArgs {
     OpenEntry *open;
     int32_t *dead;
     PcSample *samples;
+    int32_t *sample_keys;        // var_dir of every sample again, densely: what pc_apply's 2 n waves all scan
 };
 
 __device__ __forceinline__ bool lp_feasible_code(int st) { return st == 0 || st == 2; }
@@ -389,7 +390,9 @@ __global__ __launch_bounds__(256) void finish_samples(FinishArgs g) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= g.B) return;
     if (g.nprobe[k] > 0) return;
-    chain_samples(g, k, g.sum->primal_before, g.samples + g.c_cnt[2 * g.B + k]);
+    const int off = g.c_cnt[2 * g.B + k];
+    const int cnt = chain_samples(g, k, g.sum->primal_before, g.samples + off);
+    for (int q = 0; q < cnt; q++) g.sample_keys[off + q] = g.samples[off + q].var_dir;
 }
 
 struct PcApplyArgs {
@@ -397,6 +400,7 @@ struct PcApplyArgs {
     const FinishSummary *sum;    // count = sum->n_samples unless count >= 0
     int count;
     const PcSample *samples;
+    const int32_t *keys;         // samples[i].var_dir, densely (4 bytes per sample instead of a 32-byte stride)
     double *cost_l, *cost_r;
     uint8_t *has;
     int32_t *times;              // [left | right]
@@ -418,21 +422,30 @@ __global__ __launch_bounds__(64) void pc_apply(PcApplyArgs a) {
 #pragma unroll
         for (int c = 0; c < UN; c++) {
             const int i = base0 + 64 * c + lane;
-            key[c] = i < cnt ? a.samples[i].var_dir : -1;
+            key[c] = i < cnt ? a.keys[i] : -1;
         }
 #pragma unroll
         for (int c = 0; c < UN; c++) {
             const int base = base0 + 64 * c;
             unsigned long long mask = __ballot(key[c] == vd);
+            if (mask == 0ull) continue;
+            // every lane fetches its own sample of the chunk (one coalesced load); the matches are then read
+            // out of the lanes in order -- a load per match would put its latency into the serial recurrence
+            // (a frequently branched variable has thousands of samples in a step)
+            const int i = base + lane;
+            PcSample mine;
+            mine.var_dir = 0; mine.status = 1; mine.obj = 0.0; mine.bound = 0.0; mine.vc = 1.0;
+            if (i < cnt) mine = a.samples[i];
             while (mask) {
                 const int j = __ffsll((long long)mask) - 1;
                 mask &= mask - 1ull;
-                const PcSample s = a.samples[base + j];
-                if (s.status == 0 || s.status == 3) {
-                    double bc = s.obj - s.bound;
+                const int st = __builtin_amdgcn_readlane(mine.status, j);
+                if (st == 0 || st == 3) {
+                    const double obj = readlane_f64(mine.obj, j), bound = readlane_f64(mine.bound, j), vc = readlane_f64(mine.vc, j);
+                    double bc = obj - bound;
                     if (bc < 0) bc = 0;
-                    cost = (cost * (double)times + bc / s.vc) / (double)(times + 1);
-                    own_sum += bc / s.vc;
+                    cost = (cost * (double)times + bc / vc) / (double)(times + 1);
+                    own_sum += bc / vc;
                 } else {
                     own_sum += cost;
                 }

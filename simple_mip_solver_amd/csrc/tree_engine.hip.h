@@ -261,6 +261,7 @@ struct StepBuf {
     mipx::OpenEntry *d_open = nullptr;
     int32_t *d_dead = nullptr;
     mipx::PcSample *d_samples = nullptr, *h_samples = nullptr;   // h_samples: pinned staging of a host-finished step's samples
+    int32_t *d_skeys = nullptr;                  // the samples' table entries, densely (pc_apply scans them)
     char *h_fin = nullptr;                       // pinned: [summary | table block | open entries | dead rows]
     std::vector<int32_t> budget;
     int B = 0;
@@ -614,7 +615,7 @@ int launch_finish(mipx_tree *t, StepBuf &S) {
     g.budget = g.par_i + 4 * (size_t)B;
     g.pool_l = t->pool_l; g.pool_u = t->pool_u; g.pool_v = t->pool_v; g.primal = t->d_primal;
     g.c_info = S.c_info; g.c_cnt = S.c_cnt; g.c_eval = S.c_eval; g.c_val = S.c_val; g.c_flag = S.c_flag;
-    g.sum = S.d_sum; g.open = S.d_open; g.dead = S.d_dead; g.samples = S.d_samples;
+    g.sum = S.d_sum; g.open = S.d_open; g.dead = S.d_dead; g.samples = S.d_samples; g.sample_keys = S.d_skeys;
     (void)L;
     g.c_run = S.c_val + 2 * MB;
     hipLaunchKernelGGL(mipx::finish_candidates, dim3((B + 255) / 256), dim3(256), 0, st, g);
@@ -628,7 +629,7 @@ int launch_finish(mipx_tree *t, StepBuf &S) {
         hipLaunchKernelGGL(mipx::finish_samples, dim3((B + 255) / 256), dim3(256), 0, st, g);
         mipx::PcApplyArgs a;
         const TabPtr tb = tab_at(t, S.tabv);
-        a.n = t->n; a.sum = S.d_sum; a.count = -1; a.samples = S.d_samples;
+        a.n = t->n; a.sum = S.d_sum; a.count = -1; a.samples = S.d_samples; a.keys = S.d_skeys;
         a.cost_l = tb.cl; a.cost_r = tb.cr; a.has = tb.has; a.times = tb.times; a.own = tb.own;
         hipLaunchKernelGGL(mipx::pc_apply, dim3(2 * t->n), dim3(64), 0, st, a);
     }
@@ -1283,12 +1284,15 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             const size_t cnt = t->pend_samples.size();
             if (cnt > t->samples_cap) return fail(ctx, MIPX_ENOMEM, "tree: more pseudo-cost samples than the staging holds");
             std::memcpy(S.h_samples, t->pend_samples.data(), cnt * sizeof(mipx::PcSample));
+            int32_t *hk = (int32_t *)(S.h_samples + t->samples_cap);   // (the keys again, densely, behind the samples)
+            for (size_t q = 0; q < cnt; q++) hk[q] = t->pend_samples[q].var_dir;
             t->pend_samples.clear();
+            HIP_TRY(ctx, hipMemcpyAsync(S.d_skeys, hk, cnt * 4, hipMemcpyHostToDevice, t->stf));
             // (onto the version at the tail of stf's queue: every later version is copied from it)
             HIP_TRY(ctx, hipMemcpyAsync(S.d_samples, S.h_samples, cnt * sizeof(mipx::PcSample), hipMemcpyHostToDevice, t->stf));
             const TabPtr tb = tab_at(t, t->tab_tail);
             mipx::PcApplyArgs pa;
-            pa.n = n; pa.sum = nullptr; pa.count = (int)cnt; pa.samples = S.d_samples;
+            pa.n = n; pa.sum = nullptr; pa.count = (int)cnt; pa.samples = S.d_samples; pa.keys = S.d_skeys;
             pa.cost_l = tb.cl; pa.cost_r = tb.cr; pa.has = tb.has; pa.times = tb.times; pa.own = tb.own;
             hipLaunchKernelGGL(mipx::pc_apply, dim3(2 * n), dim3(64), 0, t->stf, pa);
             HIP_TRY(ctx, hipGetLastError());
@@ -2049,11 +2053,12 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
             rc |= dmalloc(ctx, &S.d_sum, 1);
             rc |= dmalloc(ctx, &S.d_open, per * B); rc |= dmalloc(ctx, &S.d_dead, per * B);
             rc |= dmalloc(ctx, &S.d_samples, t->samples_cap);
+            rc |= dmalloc(ctx, &S.d_skeys, t->samples_cap);
             const size_t fin_bytes = 128 + (t->tab_bytes + 31) / 32 * 32 + per * B * (sizeof(mipx::OpenEntry) + 4);
             if (hipEventCreateWithFlags(&S.scored, hipEventDisableTiming) != hipSuccess) rc |= MIPX_EHIP;
             if (hipHostMalloc((void **)&S.h_par, par_bytes, hipHostMallocDefault) != hipSuccess ||
                 hipHostMalloc((void **)&S.h_fin, fin_bytes, hipHostMallocDefault) != hipSuccess ||
-                hipHostMalloc((void **)&S.h_samples, t->samples_cap * sizeof(mipx::PcSample), hipHostMallocDefault) != hipSuccess)
+                hipHostMalloc((void **)&S.h_samples, t->samples_cap * (sizeof(mipx::PcSample) + 4), hipHostMallocDefault) != hipSuccess)
                 rc |= MIPX_EHIP;
         }
     }
@@ -2132,7 +2137,7 @@ void mipx_tree_destroy(mipx_tree *t) {
     if (t->h_delta) (void)hipHostFree(t->h_delta);
     if (t->ev_tab) (void)hipEventDestroy(t->ev_tab);
     for (StepBuf &S : t->buf) {
-        void *fp[] = {S.d_par, S.c_info, S.c_cnt, S.c_eval, S.c_flag, S.c_val, S.d_sum, S.d_open, S.d_dead, S.d_samples};
+        void *fp[] = {S.d_par, S.c_info, S.c_cnt, S.c_eval, S.c_flag, S.c_val, S.d_sum, S.d_open, S.d_dead, S.d_samples, S.d_skeys};
         for (void *q : fp)
             if (q) (void)hipFree(q);
         if (S.scored) (void)hipEventDestroy(S.scored);
