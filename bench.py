@@ -458,7 +458,7 @@ def other_configs(args, ctx):
                                            'inside the engine on the HBM-streaming kernel (K1b with per-node cut rows), 256 nodes per step, '
                                            'no dive (one GPU of the 8 the config names)', n=1024, m=512)
     # ---- C5 on one GPU: 1024 x 512, the HBM-streaming kernel
-    n5, m5, B5, steps5 = 1024, 512, 1024, 5
+    n5, m5, B5, steps5 = 1024, 512, 1024, 10   # (10 steps of ~68 ms: the pipeline's fill and drain are ~3 % of the region)
     A5, b5, c5, l5, u5, ints5 = random_dense_milp_arrays(n5, m5, seed=0)
     p5 = _ffi.Problem(ctx, A5, b5, c5)
     depth5 = max(1, args.dive)

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
     for (int c0 = chunk; c0 < ncuts; c0 += g.chunks * GRP) {
         int gc = 0;   // cuts in this group: c0, c0 + chunks, ...
         while (gc < GRP && c0 + gc * g.chunks < ncuts) gc++;
-        for (int q = 0; q < gc; q++) {
+        for (int q = 0; q < GRP; q++) {   // (every slot of the group: the substitution below runs over all of them)
             double *pv = pi_var + (size_t)q * (n + ms), *psq = pv + n;
             for (int j = tid; j < n; j += NT) pv[j] = 0.0;
             for (int i = tid; i < m; i += NT) psq[i] = 0.0;
@@ -410,6 +410,31 @@ __global__ __launch_bounds__(NT) void gomory_cuts(GomoryArgs g) {
 #pragma unroll
             for (int q = 0; q < kGomoryGroup; q++) acc[q] = 0.0;
             int i = 0;
+            if (GRP == kGomoryGroup && ((n + ms) & 1) == 0 && (n & 1) == 0) {
+                // a full group: every slot unconditionally (the empty ones hold zeros and are never read back), the
+                // multipliers of 8 rows x 8 cuts fetched as 16-byte LDS reads BEFORE the first multiply -- a test and
+                // an LDS wait per term made this loop 5 x longer than its multiply-adds.  Per cut and column the
+                // same terms in the same order.
+                typedef double d2s __attribute__((ext_vector_type(2)));
+                for (; i + 8 <= m0; i += 8) {
+                    double a[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) a[k] = g.A[(size_t)(i + k) * n + var];
+                    d2s p[kGomoryGroup][4];
+#pragma unroll
+                    for (int q = 0; q < kGomoryGroup; q++) {
+                        const d2s *pp = reinterpret_cast<const d2s *>(pi_var + (size_t)q * (n + ms) + n + i);
+#pragma unroll
+                        for (int h = 0; h < 4; h++) p[q][h] = pp[h];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+#pragma unroll
+                        for (int q = 0; q < kGomoryGroup; q++)
+                            acc[q] = acc[q] + a[k] * ((k & 1) ? p[q][k >> 1].y : p[q][k >> 1].x);
+                    }
+                }
+            }
             for (; i + 8 <= m0; i += 8) {   // (the loads of 8 rows are issued before the first is consumed)
                 double a[8];
 #pragma unroll

@@ -253,7 +253,6 @@ struct StepBuf {
     // children may take go up with the batch, a summary + compact lists come back
     bool fast = false;
     int tabv = 0;                                // the table version this step's finish writes
-    hipEvent_t scored = nullptr;                 // K4 of the step is queued: the finish (stf) waits for it
     char *d_par = nullptr, *h_par = nullptr;     // [par_d (2 MB f64) | par_i (4 MB i32) | budget (per MB i32)]
     int32_t *c_info = nullptr, *c_cnt = nullptr, *c_eval = nullptr, *c_flag = nullptr;
     double *c_val = nullptr;
@@ -295,8 +294,11 @@ struct mipx_tree {
     // version of the last step the HOST has finished -- complete by then, never written again while a
     // kernel in flight reads it, and the same version in every run.
     int tab_tail = 0, tab_host = 0;
-    hipEvent_t ev_tab = nullptr;     // samples / merges queued on stf behind the last finished step
-    bool tab_pending = false;
+    // Samples of a host-finished node / an exchange's merge are applied LATE, to the version at the tail of stf's
+    // queue at that time: ev_tab[v] / tab_late[v] say that version v got such an update and when it is complete.
+    // Only a launch that reads that very version waits for it (in the pipeline a launch reads an older one).
+    hipEvent_t ev_tab[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool tab_late[8] = {false, false, false, false, false, false, false, false};
     double *h_delta = nullptr, *d_delta = nullptr;   // exchange: the other ranks' new samples (4 staging slots)
     int delta_turn = 0;
     std::vector<double> pc_others_prev;
@@ -600,6 +602,7 @@ int launch_finish(mipx_tree *t, StepBuf &S) {
     const int prev = t->tab_tail;
     S.tabv = (prev + 1) % kTabV;
     t->tab_tail = S.tabv;
+    t->tab_late[S.tabv] = false;   // (written afresh: a copy of the tail, which holds every late update queued so far)
     if (t->rule == 1)
         HIP_TRY(ctx, hipMemcpyAsync(tab_at(t, S.tabv).cl, tab_at(t, prev).cl, t->tab_bytes, hipMemcpyDeviceToDevice, st));
     const int B = S.B, L = t->dive + 1;
@@ -713,9 +716,9 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
         const int trc = table_replace(t);
         if (trc) return trc;
     }
-    if (t->fast_ok && t->tab_pending) {   // samples of a host-finished step / a merge on their way into the version read below
-        HIP_TRY(ctx, hipStreamWaitEvent(st, t->ev_tab, 0));
-        t->tab_pending = false;
+    if (t->fast_ok && t->tab_late[t->tab_host]) {   // late samples / a merge on their way into the version read below
+        HIP_TRY(ctx, hipStreamWaitEvent(st, t->ev_tab[t->tab_host], 0));
+        t->tab_late[t->tab_host] = false;
     }
     if (t->table_dirty) {  // pseudo-cost table as of the last finished step
         const size_t n = t->n;
@@ -1296,8 +1299,8 @@ int tree_finish(mipx_tree *t, StepBuf &S, bool overlapped) {
             pa.cost_l = tb.cl; pa.cost_r = tb.cr; pa.has = tb.has; pa.times = tb.times; pa.own = tb.own;
             hipLaunchKernelGGL(mipx::pc_apply, dim3(2 * n), dim3(64), 0, t->stf, pa);
             HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipEventRecord(t->ev_tab, t->stf));
-            t->tab_pending = true;
+            HIP_TRY(ctx, hipEventRecord(t->ev_tab[t->tab_tail], t->stf));
+            t->tab_late[t->tab_tail] = true;
         }
         if (t->fast_ok) t->tab_host = S.fast ? S.tabv : t->tab_tail;
         if (changed && (!overlapped || total > 0)) {
@@ -1806,8 +1809,8 @@ int x_apply(mipx_tree *t, const char *gathered, bool last) {
             ma.n = t->n; ma.delta = dd; ma.cost_l = tb.cl; ma.cost_r = tb.cr; ma.has = tb.has; ma.times = tb.times;
             hipLaunchKernelGGL(mipx::pc_merge, dim3((2 * t->n + 255) / 256), dim3(256), 0, t->stf, ma);
             HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipEventRecord(t->ev_tab, t->stf));
-            t->tab_pending = true;
+            HIP_TRY(ctx, hipEventRecord(t->ev_tab[t->tab_tail], t->stf));
+            t->tab_late[t->tab_tail] = true;
         }
     } else if (t->rule == 1) {
         for (size_t j = 0; j < n; j++) {
@@ -2042,8 +2045,10 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
     if (t->fast_ok) {
         const size_t per = 2 * LC;
         rc |= dmalloc(ctx, &t->d_delta, 4 * 4 * n);
-        if (hipHostMalloc((void **)&t->h_delta, 4 * 4 * n * 8, hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&t->ev_tab, hipEventDisableTiming) != hipSuccess) rc |= MIPX_EHIP;
+        if (hipHostMalloc((void **)&t->h_delta, 4 * 4 * n * 8, hipHostMallocDefault) != hipSuccess) rc |= MIPX_EHIP;
+        static_assert(kTabV == 8, "ev_tab / tab_late are sized for the version ring");
+        for (int v = 0; v < kTabV; v++)
+            if (hipEventCreateWithFlags(&t->ev_tab[v], hipEventDisableTiming) != hipSuccess) rc |= MIPX_EHIP;
         t->samples_cap = (size_t)t->probe_cap + LC * B;
         for (StepBuf &S : t->buf) {
             const size_t par_bytes = 2 * B * 8 + (4 * B + per * B) * 4;
@@ -2055,7 +2060,6 @@ int mipx_tree_create_ex(mipx_problem *p, const int32_t *int_idx, int n_int, cons
             rc |= dmalloc(ctx, &S.d_samples, t->samples_cap);
             rc |= dmalloc(ctx, &S.d_skeys, t->samples_cap);
             const size_t fin_bytes = 128 + (t->tab_bytes + 31) / 32 * 32 + per * B * (sizeof(mipx::OpenEntry) + 4);
-            if (hipEventCreateWithFlags(&S.scored, hipEventDisableTiming) != hipSuccess) rc |= MIPX_EHIP;
             if (hipHostMalloc((void **)&S.h_par, par_bytes, hipHostMallocDefault) != hipSuccess ||
                 hipHostMalloc((void **)&S.h_fin, fin_bytes, hipHostMallocDefault) != hipSuccess ||
                 hipHostMalloc((void **)&S.h_samples, t->samples_cap * (sizeof(mipx::PcSample) + 4), hipHostMallocDefault) != hipSuccess)
@@ -2135,12 +2139,12 @@ void mipx_tree_destroy(mipx_tree *t) {
     if (t->d_primal) (void)hipFree(t->d_primal);
     if (t->d_delta) (void)hipFree(t->d_delta);
     if (t->h_delta) (void)hipHostFree(t->h_delta);
-    if (t->ev_tab) (void)hipEventDestroy(t->ev_tab);
+    for (hipEvent_t e : t->ev_tab)
+        if (e) (void)hipEventDestroy(e);
     for (StepBuf &S : t->buf) {
         void *fp[] = {S.d_par, S.c_info, S.c_cnt, S.c_eval, S.c_flag, S.c_val, S.d_sum, S.d_open, S.d_dead, S.d_samples, S.d_skeys};
         for (void *q : fp)
             if (q) (void)hipFree(q);
-        if (S.scored) (void)hipEventDestroy(S.scored);
         if (S.h_par) (void)hipHostFree(S.h_par);
         if (S.h_fin) (void)hipHostFree(S.h_fin);
         if (S.h_samples) (void)hipHostFree(S.h_samples);
