@@ -479,6 +479,10 @@ typedef struct mipx_tree_global_stats_t {
 } mipx_tree_global_stats_t;
 int mipx_tree_global_stats(mipx_tree *t, mipx_tree_global_stats_t *out);
 
+/* Device time of the LP kernel launch inside the last mipx_lp_solve_multi call on this context (HIP events on
+ * its stream, ms; -1 if none): the rate with the inputs resident in HBM, beside the call's wall time which
+ * includes the PCIe copies of its host buffers. */
+int mipx_last_kernel_ms(mipx_ctx *ctx, float *ms);
 /* Name of the kernel instantiation that (m, n) dispatches to, e.g. "lp_dual_simplex<7,5,16>". */
 int mipx_kernel_name(int m, int n, char *buf, size_t buflen);
 

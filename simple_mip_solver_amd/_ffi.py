@@ -25,7 +25,7 @@ SYMBOLS = [
     'mipx_comm_destroy', 'mipx_comm_rank', 'mipx_comm_size', 'mipx_comm_allgather', 'mipx_comm_barrier',
     'mipx_tree_set_comm', 'mipx_tree_global_stats', 'mipx_exchange_record_len', 'mipx_exchange_decide',
     'mipx_tree_exchange_record', 'mipx_tree_trace_cuts', 'mipx_tree_peek_cuts', 'mipx_tree_cut_store',
-    'mipx_tree_cut_rows_per_node', 'mipx_tree_migrate_self', 'mipx_tree_kernel_ms',
+    'mipx_tree_cut_rows_per_node', 'mipx_tree_migrate_self', 'mipx_tree_kernel_ms', 'mipx_last_kernel_ms',
     'mipx_dev_alloc', 'mipx_dev_free',
     'mipx_memcpy_h2d', 'mipx_memcpy_d2h', 'mipx_timer_start', 'mipx_timer_stop',
     'mipx_kernel_name', 'mipx_debug_enable', 'mipx_debug_read',
@@ -323,6 +323,14 @@ class Context:
 
     def sync(self):
         self.check(lib().mipx_ctx_sync(self._h), 'mipx_ctx_sync')
+
+    def last_kernel_ms(self):
+        """Device time of the LP launch inside the last solve_multi call (mipx_last_kernel_ms)."""
+        ms = C.c_float()
+        L = lib()
+        L.mipx_last_kernel_ms.argtypes = [_vp, C.POINTER(C.c_float)]
+        self.check(L.mipx_last_kernel_ms(self._h, C.byref(ms)), 'mipx_last_kernel_ms')
+        return float(ms.value)
 
     def timer_start(self):
         self.check(lib().mipx_timer_start(self._h), 'mipx_timer_start')

@@ -18,6 +18,8 @@ struct mipx_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t k0 = nullptr, k1 = nullptr;   // around the LP launch of the last host-buffer call (mipx_last_kernel_ms)
+    float last_kernel_ms = -1.f;
     std::string err;
     // staging of the host-buffer cut entry points, grown on demand (a hipMalloc / hipFree pair per
     // call cost more than the kernels between them)
@@ -221,6 +223,8 @@ void mipx_ctx_destroy(mipx_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->k0) (void)hipEventDestroy(ctx->k0);
+    if (ctx->k1) (void)hipEventDestroy(ctx->k1);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -619,8 +623,12 @@ int mipx_lp_solve_multi(mipx_ctx *ctx, int m, int n, int batch, const double *A,
         a.x = (double *)(base + o_x); a.y = nullptr; a.vstat_out = (int8_t *)(base + o_v);
         a.iters = (int32_t *)(base + o_it); a.npivots = (int32_t *)(base + o_np); a.batch = batch;
         a.dbg_T = nullptr; a.dbg_vec = nullptr; a.dbg_idx = nullptr; a.dbg_all = 0;
+        if (!ctx->k0 && (hipEventCreate(&ctx->k0) != hipSuccess || hipEventCreate(&ctx->k1) != hipSuccess))
+            rc = fail(ctx, MIPX_EHIP, "mipx_lp_solve_multi: events");
+        if (rc == MIPX_OK) (void)hipEventRecord(ctx->k0, st);
         cfg->launch(a, batch, st);
         if (hipGetLastError() != hipSuccess) rc = fail(ctx, MIPX_EHIP, "mipx_lp_solve_multi: launch");
+        if (rc == MIPX_OK) (void)hipEventRecord(ctx->k1, st);
     }
     auto down = [&](void *dst, size_t o, size_t bytes) {
         if (dst && rc == MIPX_OK && hipMemcpyAsync(dst, base + o, bytes, hipMemcpyDeviceToHost, st) != hipSuccess)
@@ -629,6 +637,8 @@ int mipx_lp_solve_multi(mipx_ctx *ctx, int m, int n, int batch, const double *A,
     down(status, o_st, B * 4); down(obj, o_obj, B * 8); down(x, o_x, B * nn * 8);
     down(vstat_out, o_v, B * nv); down(iters, o_it, B * 4); down(npivots, o_np, B * 4);
     if (hipStreamSynchronize(st) != hipSuccess && rc == MIPX_OK) rc = fail(ctx, MIPX_EHIP, "mipx_lp_solve_multi: sync");
+    ctx->last_kernel_ms = -1.f;
+    if (rc == MIPX_OK && hipEventElapsedTime(&ctx->last_kernel_ms, ctx->k0, ctx->k1) != hipSuccess) ctx->last_kernel_ms = -1.f;
     (void)hipFree(base);
     return rc;
 }
@@ -894,6 +904,12 @@ int mipx_timer_stop(mipx_ctx *ctx, float *ms) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
     HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return MIPX_OK;
+}
+
+int mipx_last_kernel_ms(mipx_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return MIPX_EINVAL;
+    *ms = ctx->last_kernel_ms;
     return MIPX_OK;
 }
 
