@@ -13,6 +13,7 @@
 #include "../../include/mipx.h"
 #include "lp_kernel.hip.h"
 #include "lp_kernel_big.hip.h"
+#include "lp_kernel_root.hip.h"
 
 struct mipx_ctx {
     int device = -1;
@@ -43,6 +44,7 @@ struct mipx_problem {
     double *big_scratch2 = nullptr;   // launches beside the main stream's (the engine's probes) stream their own slabs
     int big_slabs2 = 0;
     int big_rows = 0;                 // rows per slab (m, or m + cut rows once a launch carried them)
+    char *root_state = nullptr;       // K1c (one cold LP over the chip): its buffers, allocated on first use
     // anchor tableau (mipx_problem_set_anchor): warm starts refactor from it
     double *anchor_T = nullptr, *anchor_vec = nullptr;
     int32_t *anchor_idx = nullptr;
@@ -104,6 +106,71 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 bool big_fits(int m, int n) { return m >= 1 && m <= mipx::kBigMaxM && n <= mipx::kBigMaxN; }
 bool shape_supported(int m, int n) { return pick_cfg(m, n) != nullptr || big_fits(m, n); }
 
+// K1c: one cold node LP (no warm-start basis) above the register tiles, its rows dealt out to G workgroups, one
+// launch per pivot (lp_kernel_root.hip.h).  The host queues the pivots in chunks and looks at the status word
+// between them.  Returns MIPX_OK with *done = false where it does not apply.
+int launch_root_coop(mipx_problem *p, mipx::LpArgs &a, hipStream_t stream, bool *done) {
+    *done = false;
+    mipx_ctx *ctx = p->ctx;
+    const int m = p->m, n = p->n;
+    if (a.batch != 1 || a.vstat_in != nullptr || a.ncut != nullptr || a.refactor_only || m < 64 || n > mipx::kBigMaxN ||
+        a.A_stride != 0 || (a.dbg_T && a.dbg_all) || (getenv("MIPX_NO_COOP_ROOT") && atoi(getenv("MIPX_NO_COOP_ROOT"))))
+        return MIPX_OK;
+    int32_t src = 0;
+    if (a.slot) {
+        HIP_TRY(ctx, hipMemcpyAsync(&src, a.slot, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+    }
+    // at most 256 workgroups (one candidate per thread of a workgroup), RPB = 1, 2, 4 or 8 rows of the tableau in
+    // the registers of each
+    int gmax = getenv("MIPX_ROOT_WG") ? atoi(getenv("MIPX_ROOT_WG")) : 256;
+    gmax = gmax < 32 ? 32 : gmax > 256 ? 256 : gmax;
+    int RPB = 1;
+    while (RPB < 8 && (m + RPB - 1) / RPB > gmax) RPB *= 2;
+    const int G = (m + RPB - 1) / RPB;
+    if (G > 256) return MIPX_OK;
+    const size_t nn = (size_t)n, mm = (size_t)m;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_T = carve(mm * nn * 8), o_b0 = carve(mm * 8), o_ba = carve(mm * 8), o_bb = carve(mm * 8),
+                 o_w = carve(mm * 8), o_rl = carve(mm * 8), o_ru = carve(mm * 8), o_bv = carve(mm * 4), o_d = carve(2 * nn * 8), o_va = carve(2 * nn * 8),
+                 o_vb = carve(2 * nn * 8), o_nv = carve(2 * nn * 4), o_sd = carve(2 * nn * 4),
+                 o_ck = carve(2 * (size_t)G * sizeof(mipx::RootKey)), o_cr = carve(2 * (size_t)G * sizeof(mipx::RootRow)), o_row = carve(2 * (size_t)G * nn * 8),
+                 o_ctl = carve(16 * 4);
+    if (!p->root_state) HIP_TRY(ctx, hipMalloc((void **)&p->root_state, off));
+    char *base = p->root_state;
+    mipx::RootState S;
+    S.m = m; S.n = n; S.G = G; S.RPB = RPB;
+    S.T = (double *)(base + o_T); S.beta0 = (double *)(base + o_b0); S.ba = (double *)(base + o_ba);
+    S.bb = (double *)(base + o_bb); S.wgt = (double *)(base + o_w); S.bvar = (int *)(base + o_bv);
+    S.rlo = (double *)(base + o_rl); S.rup = (double *)(base + o_ru);
+    S.d = (double *)(base + o_d); S.va = (double *)(base + o_va); S.vb = (double *)(base + o_vb);
+    S.nvar = (int *)(base + o_nv); S.side = (int *)(base + o_sd);
+    S.ckey = (mipx::RootKey *)(base + o_ck); S.crow = (mipx::RootRow *)(base + o_cr); S.rowbuf = (double *)(base + o_row); S.ctl = (int *)(base + o_ctl);
+    S.lo = a.l + (size_t)src * nn; S.up = a.u + (size_t)src * nn;
+    S.max_iter = a.max_iter; S.cap = 100 * (m + n) + 1000;
+    hipLaunchKernelGGL(mipx::lp_root_init, dim3(G), dim3(mipx::kRootNT), 2 * nn * 8, stream, S, a.A, a.b, a.c);
+    HIP_TRY(ctx, hipGetLastError());
+    int par = 0;
+    const int chunk = 192;
+    void (*pivot)(mipx::RootState, int) = RPB == 1 ? mipx::lp_root_pivot<1> : RPB == 2 ? mipx::lp_root_pivot<2>
+                                           : RPB == 4 ? mipx::lp_root_pivot<4> : mipx::lp_root_pivot<8>;
+    const long limit = (long)S.cap + 8;
+    for (long done_pivots = 0; done_pivots <= limit; done_pivots += chunk) {
+        for (int k = 0; k < chunk; k++, par ^= 1)
+            hipLaunchKernelGGL(pivot, dim3(G), dim3(mipx::kRootNT), 0, stream, S, par);
+        HIP_TRY(ctx, hipGetLastError());
+        int32_t st = -1;
+        HIP_TRY(ctx, hipMemcpyAsync(&st, S.ctl + 8 * par, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
+        if (st >= 0) break;
+    }
+    hipLaunchKernelGGL(mipx::lp_root_final, dim3(1), dim3(mipx::kRootNT), nn * 8, stream, S, par, a, (size_t)0);
+    HIP_TRY(ctx, hipGetLastError());
+    *done = true;
+    return MIPX_OK;
+}
+
 // Launch K1 (register-resident tableau) or, above its tiles, K1b (tableau streamed from HBM).
 // m_rows: the largest row count of any node of the launch when nodes carry cut rows (a.ncut), so
 // that the tile covers it (results do not depend on the tile); -1: the problem's own m.
@@ -149,6 +216,11 @@ int launch_lp_any(mipx_problem *p, mipx::LpArgs &a, int batch, hipStream_t strea
         HIP_TRY(ctx, hipGetLastError());
         return MIPX_OK;
 #endif
+    }
+    {   // one cold LP: over the whole chip instead of one CU
+        bool done = false;
+        const int rrc = launch_root_coop(p, a, stream, &done);
+        if (rrc || done) return rrc;
     }
     // rows a node can have: the shared ones, or (cut rows) the rows allotted per node
     const int mcap = a.ncut ? a.mstride : p->m;
@@ -280,6 +352,7 @@ void mipx_problem_destroy(mipx_problem *p) {
     if (p->dbg_idx) (void)hipFree(p->dbg_idx);
     if (p->big_scratch) (void)hipFree(p->big_scratch);
     if (p->big_scratch2) (void)hipFree(p->big_scratch2);
+    if (p->root_state) (void)hipFree(p->root_state);
     if (p->anchor_T) (void)hipFree(p->anchor_T);
     if (p->anchor_vec) (void)hipFree(p->anchor_vec);
     if (p->anchor_idx) (void)hipFree(p->anchor_idx);

@@ -144,6 +144,55 @@ def test_hbm_streaming_kernel_full_solves(n, m, seed, gpu_ctx, oracle):
     assert_same(p.solve_batch(L, U, V, max_iter=5), oracle.lp_solve_batch(A, b, c, L, U, V, max_iter=5), 'probes')
 
 
+@pytest.mark.parametrize('n,m,seed', [(300, 150, 0), (512, 256, 1), (600, 70, 0), (1024, 512, 0), (1000, 1000, 2)])
+def test_one_cold_lp_over_the_chip(n, m, seed, gpu_ctx, oracle, monkeypatch):
+    """K1c (lp_kernel_root.hip.h): a single cold LP above the register tiles is spread over up to 256
+    workgroups, one launch per pivot.  Same arithmetic and selection rules as K1b: the full solve is the
+    oracle's bit for bit, whatever the number of rows each workgroup holds (MIPX_ROOT_WG 32: eight rows,
+    64: ..., 256: the default), and it is K1b's (MIPX_NO_COOP_ROOT=1) -- states after k pivots included."""
+    A, b, c, l, u, _ = random_dense_milp_arrays(n, m, seed=seed)
+    want = oracle.lp_solve_batch(A, b, c, l[None], u[None])
+    p = _ffi.Problem(gpu_ctx, A, b, c)
+    for wg in ('256', '128', '64', '32'):
+        if (m + int(wg) - 1) // int(wg) > 8:
+            continue
+        monkeypatch.setenv('MIPX_ROOT_WG', wg)
+        q = _ffi.Problem(gpu_ctx, A, b, c)       # (its buffers are sized for the number of workgroups)
+        assert_same(q.solve_batch(l[None], u[None]), want, f'cold root, at most {wg} workgroups')
+        q.close()
+    monkeypatch.delenv('MIPX_ROOT_WG')
+    for k in (1, 2, 33):
+        g = p.solve_batch(l[None], u[None], max_iter=k)
+        assert_same(g, oracle.lp_solve_batch(A, b, c, l[None], u[None], max_iter=k), f'{k} pivots')
+        monkeypatch.setenv('MIPX_NO_COOP_ROOT', '1')
+        assert_same(p.solve_batch(l[None], u[None], max_iter=k), g, f'{k} pivots, one workgroup')
+        monkeypatch.delenv('MIPX_NO_COOP_ROOT')
+    p.close()
+
+
+@pytest.mark.parametrize('n,m', [(257, 100), (300, 64), (520, 260), (700, 300)])
+def test_one_cold_lp_over_the_chip_statuses(n, m, gpu_ctx, oracle, monkeypatch):
+    """... on instances with fixed variables, infinite bounds and an empty row, and on an infeasible and an
+    unbounded one: status, basis, x, duals as the oracle's."""
+    A, b, c, l, u = _mixed_instance(n, m, seed=n + m)
+    p = _ffi.Problem(gpu_ctx, A, b, c)
+    assert_same(p.solve_batch(l[None], u[None]), oracle.lp_solve_batch(A, b, c, l[None], u[None]), 'mixed')
+    b2 = b.copy(); A2 = A.copy()
+    A2[1] = -1.0; b2[1] = 1.0; l2 = np.zeros(n)                    # -sum x >= 1 with x >= 0: infeasible
+    p2 = _ffi.Problem(gpu_ctx, A2, b2, c)
+    g = p2.solve_batch(l2[None], u[None])
+    assert_same(g, oracle.lp_solve_batch(A2, b2, c, l2[None], u[None]), 'infeasible')
+    assert g['status'][0] == 1
+    c3 = c.copy(); A3 = A.copy(); u3 = u.copy()
+    c3[0] = -1.0; A3[:, 0] = 0.0; u3[0] = INF                      # a free ride down column 0: unbounded
+    p3 = _ffi.Problem(gpu_ctx, A3, b, c3)
+    g = p3.solve_batch(l[None], u3[None])
+    assert_same(g, oracle.lp_solve_batch(A3, b, c3, l[None], u3[None]), 'unbounded')
+    assert g['status'][0] in (1, 2)
+    for q in (p, p2, p3):
+        q.close()
+
+
 def test_s5_shape_1024x512(gpu_ctx, oracle):
     """BASELINE config C5 shape: 1024 vars x 512 rows.  The cold root needs tens of thousands of
     pivots, so parity is checked on truncated solves (every state after k pivots must agree) and on
