@@ -86,6 +86,11 @@
 #define ST_LOWER 3
 
 /* optional dump of the final simplex state (set by tests through mipx_oracle_set_dump) */
+/* The M component of a value a + b M is a combination of tableau entries with 0/1 weights: what is left of it
+ * below MIPX_BTOL after an update is rounding noise, and is taken out at once -- left in, it piles up over
+ * thousands of pivots until the zero tests see a symbolic violation that is not there (and the report would
+ * multiply it by MIPX_MREPORT).  A no-op on an LP with finite bounds: every b is exactly 0 there. */
+static inline double snap_m(double v) { return fabs(v) <= 1e-9 ? 0.0 : v; }
 static double *g_dump_T = 0, *g_dump_vec = 0;
 static int32_t *g_dump_idx = 0;
 void mipx_oracle_set_dump(double *T, double *vec, int32_t *idx) {
@@ -304,7 +309,7 @@ static int lp_solve_impl(int m, int n, const double *A, const double *b, const d
         ba[i] = t.beta0[i] - fold_sum(buf, n2);
         for (int j = 0; j < n; j++) buf[j] = Ti[j] * vb[j];
         for (int j = n; j < n2; j++) buf[j] = 0.0;
-        bb[i] = 0.0 - fold_sum(buf, n2);
+        bb[i] = snap_m(0.0 - fold_sum(buf, n2));
     }
 
     /* 3'. dual steepest edge weights (pricing 1): squared norms of the rows of [I | T] */
@@ -324,6 +329,23 @@ static int lp_solve_impl(int m, int n, const double *A, const double *b, const d
         }
     }
 
+#define VALUES_FROM_TABLEAU() do { \
+    for (int i_ = 0; i_ < m; i_++) { \
+        const double *Ti_ = t.T + (size_t)i_ * n; \
+        for (int j = 0; j < n; j++) buf[j] = Ti_[j] * va[j]; \
+        for (int j = n; j < n2; j++) buf[j] = 0.0; \
+        ba[i_] = t.beta0[i_] - fold_sum(buf, n2); \
+        for (int j = 0; j < n; j++) buf[j] = Ti_[j] * vb[j]; \
+        for (int j = n; j < n2; j++) buf[j] = 0.0; \
+        bb[i_] = snap_m(0.0 - fold_sum(buf, n2)); \
+    } } while (0)
+    /* Above the register tiles (the shapes of K1b / K1c: long cold solves) a verdict -- optimal, unbounded,
+     * infeasible -- of a solve that has carried symbolic values is only taken on values worked out afresh from
+     * the tableau: the running updates of thousands of pivots are not trusted with it.  (An LP with finite
+     * bounds never carries one: nothing changes for it.) */
+    const int refresh = devex;
+    int fresh = 1, sym = 0;
+    for (int j = 0; j < n; j++) if (vb[j] != 0.0) sym = 1;
     /* 3. dual simplex */
     int iters = 0, status = -1;
     int degen = 0; /* consecutive degenerate steps; > m+n switches to Bland's rule (anti-cycling) */
@@ -359,6 +381,7 @@ next_pass:
             else better = v < rvar;
             if (better) { r = i; rlevel = level; rviol = viol; rvar = v; sigma = sg; }
         }
+        if (r < 0 && refresh && sym && !fresh) { VALUES_FROM_TABLEAU(); fresh = 1; continue; }
         if (r < 0) {
             status = 0;
             for (int i = 0; i < m; i++) if (bb[i] > MIPX_BTOL) status = 2;
@@ -381,6 +404,7 @@ next_pass:
                 thmax = ratio; jmin = j; jminvar = v;
             }
         }
+        if (jmin < 0 && refresh && sym && !fresh) { VALUES_FROM_TABLEAU(); fresh = 1; continue; }
         if (jmin < 0) { status = 1; break; }
         /* pass 2: largest |a| among columns with dj <= thmax*|a| (the pass-1 argmin always
          * qualifies); ties -> lowest variable index */
@@ -444,14 +468,15 @@ next_pass:
                 if (i == r) continue;
                 double al = t.T[(size_t)i * n + q];
                 ba[i] = fma(-al, ta, ba[i]);
-                bb[i] = fma(-al, tb, bb[i]);
+                bb[i] = snap_m(fma(-al, tb, bb[i]));
             }
             ba[r] = va[q] + ta;
-            bb[r] = vb[q] + tb;
+            bb[r] = snap_m(vb[q] + tb);
             tab_pivot(&t, r, q);
             nb_up[q] = (int8_t)newside;
             va[q] = la; vb[q] = lb;
-            iters++; npiv++;
+            iters++; npiv++; fresh = 0;
+            if (lb != 0.0) sym = 1;
             if (dse && ++wage == MIPX_DSE_REFRESH) { /* exact again, from the tableau after the pivot */
                 wage = 0;
                 for (int i = 0; i < m; i++) {
@@ -486,7 +511,7 @@ done:
         }
         for (int i = 0; i < m; i++) {
             int v = t.bvar[i];
-            if (v < n) x[v] = fma(bb[i], MIPX_MREPORT, ba[i]);
+            if (v < n) x[v] = fma(snap_m(bb[i]), MIPX_MREPORT, ba[i]);
         }
         if (status == 1) dive_obj = INFINITY;
         else {

@@ -190,6 +190,12 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 }
 constexpr int kNoCand = 0x7fffffff;
 // lane-local "keep the better candidate": larger key wins, ties go to the smaller payload
+// The M component of a value a + b M is a combination of tableau entries with 0/1 weights: what an update
+// leaves of it below kBTol is rounding noise and is taken out at once.  Left in, it piles up over thousands
+// of pivots until the zero tests see a symbolic violation that is not there, and the report multiplies it by
+// kMReport.  A no-op on an LP with finite bounds (every b is exactly 0 there).
+__device__ __forceinline__ double snap_m(double v) { return fabs(v) <= kBTol ? 0.0 : v; }
+
 __device__ __forceinline__ void keep(double &bk, int &bp, double k, int p, bool valid) {
     const bool b = valid && (k > bk || (k == bk && p < bp));
     bk = b ? k : bk;
@@ -1135,7 +1141,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                 }
                 if (cl == 0) {
 #pragma unroll
-                    for (int ii = 0; ii < R; ii++) s.bb[MIPX_ROW(ii)] = 0.0 - (s0[ii] + s1[ii]);
+                    for (int ii = 0; ii < R; ii++) s.bb[MIPX_ROW(ii)] = snap_m(0.0 - (s0[ii] + s1[ii]));
                 }
             }
             MIPX_EXACT_WEIGHTS();   // the steepest-edge weights the solve starts with
@@ -1319,7 +1325,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                         wn = wn < 1.0 ? 1.0 : wn;
                         rB0[kk] = pr ? rhon : u0;
                         rBa[kk] = pr ? vaq + ta : u1;
-                        rBb[kk] = pr ? vbq + tb : u2;
+                        rBb[kk] = snap_m(pr ? vbq + tb : u2);
                         rW[kk] = pr ? wrn : wn;
                         rM[kk] = pr ? (ev << 2) : rM[kk];
                         rLo[kk] = pr ? elo : rLo[kk];

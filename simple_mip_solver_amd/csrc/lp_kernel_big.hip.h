@@ -125,6 +125,10 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
         __syncthreads();
         const int nw = __builtin_amdgcn_readfirstlane(s_ci[4]);
         int npiv = 0, iters = 0, status = -1, phase = vin ? 0 : 1, w = 0, degen = 0;
+        // a verdict (optimal / unbounded / infeasible) of a solve that has carried symbolic values a + b M is only
+        // taken on values worked out afresh from the tableau (phase 3): the running updates of thousands of pivots
+        // are not trusted with it.  An LP with finite bounds never carries one: nothing changes for it.
+        int sym = 0, fresh = 1;
         const int cap = 100 * (m + n) + 1000;
         const bool ctl = tid < CT;
         // in-place dive (LpArgs::dive, like K1): pass 0 the node, pass 1 one child on the same slab
@@ -177,7 +181,9 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                 if (r < 0) continue;
                 pinv = s_cd[0];
                 for (int j = tid; j < n; j += NT) s_row[j] = T[(size_t)r * n + j];
-            } else if (phase == 1) {
+            } else if (phase == 1 || phase == 3) {
+                int anyb = 0;
+                if (phase == 1)
                 for (int j = tid; j < n; j += NT) {
                     const int v = s_nvar[j];
                     const double lo = v < n ? s_lo[v] : 0.0, up = v < n ? s_up[v] : INF;
@@ -190,8 +196,9 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                     s_side[j] = side;
                     s_va[j] = side == 0 ? lo : side == 1 ? up : 0.0;
                     s_vb[j] = side == 2 ? 1.0 : 0.0;
+                    anyb |= side == 2;
                 }
-                __syncthreads();
+                if (phase == 1) sym = __syncthreads_or(anyb); else __syncthreads();
                 // beta = beta0 - T v  (fold-in-half tree over n2; lane holds j = lane + 64 k)
                 for (int i = wave; i < m; i += NW) {
                     const double *Ti = T + (size_t)i * n;
@@ -214,11 +221,13 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                         sa = sa + __shfl_down(sa, h, 64);
                         sb = sb + __shfl_down(sb, h, 64);
                     }
-                    if (lane == 0) { s_ba[i] = s_beta0[i] - sa; s_bb[i] = 0.0 - sb; }
+                    if (lane == 0) { s_ba[i] = s_beta0[i] - sa; s_bb[i] = snap_m(0.0 - sb); }
                 }
-                for (int i = tid; i < m; i += NT) s_wgt[i] = 1.0;   // Devex: a fresh reference framework
+                if (phase == 1)
+                    for (int i = tid; i < m; i += NT) s_wgt[i] = 1.0;   // Devex: a fresh reference framework
                 __syncthreads();
                 phase = 2;
+                fresh = 1;
                 continue;
             } else {
                 const bool bland = degen > m + n;
@@ -270,6 +279,7 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                 __syncthreads();
                 {
                     const int cmd = __builtin_amdgcn_readfirstlane(s_ci[0]);
+                    if (cmd && cmd != 4 && sym && !fresh) { phase = 3; continue; }
                     if (cmd) { status = cmd == 1 ? 0 : cmd == 3 ? 2 : 3; break; }
                     const int win = __builtin_amdgcn_readfirstlane(s_ci[1]);
                     r = win & 0x7fff;
@@ -331,6 +341,7 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                 }
                 __syncthreads();
                 q = __builtin_amdgcn_readfirstlane(s_ci[0]);
+                if (q < 0 && sym && !fresh) { phase = 3; continue; }
                 if (q < 0) { status = 1; break; }
                 pinv = s_cd[0];
                 for (int i = tid; i < m; i += NT) s_alpha[i] = T[(size_t)i * n + q];
@@ -338,7 +349,8 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                 const double lo = lv < n ? s_lo[lv] : 0.0, up = lv < n ? s_up[lv] : INF;
                 if (sigma > 0) { la = lo; lb = 0.0; newside = 0; }
                 else if (!isinf(up)) { la = up; lb = 0.0; newside = 1; }
-                else { la = 0.0; lb = 1.0; newside = 2; }
+                else { la = 0.0; lb = 1.0; newside = 2; sym = 1; }
+                fresh = 0;
             }
             const double dq = s_d[q], b0r = s_beta0[r];
             const double bar = s_ba[r], bbr = s_bb[r], vaq = s_va[q], vbq = s_vb[q];
@@ -421,14 +433,14 @@ __global__ __launch_bounds__(kBigNT) void lp_dual_simplex_big(LpArgs g, double *
                     if (i == r) {
                         s_beta0[i] = rhon;
                         if (vals) {
-                            s_ba[i] = vaq + ta; s_bb[i] = vbq + tb;
+                            s_ba[i] = vaq + ta; s_bb[i] = snap_m(vbq + tb);
                             const double w = (wr * pinv) * pinv;
                             s_wgt[i] = w < 1.0 ? 1.0 : w;
                         }
                     } else {
                         s_beta0[i] = fma(-a, rhon, s_beta0[i]);
                         if (vals) {
-                            s_ba[i] = fma(-a, ta, s_ba[i]); s_bb[i] = fma(-a, tb, s_bb[i]);
+                            s_ba[i] = fma(-a, ta, s_ba[i]); s_bb[i] = snap_m(fma(-a, tb, s_bb[i]));
                             const double ratio = a * pinv;
                             const double w = (ratio * ratio) * wr;
                             s_wgt[i] = w > s_wgt[i] ? w : s_wgt[i];

@@ -62,9 +62,10 @@ __device__ __forceinline__ bool root_better(int la, double va, int pa, int lb, d
     return la > lb || (la == lb && la > 0 && (va > vb || (va == vb && pa < pb)));
 }
 
-// the candidate of rows [i0, i1) out of global memory (launch 0): one wave scans them, lane 0 publishes
-__device__ inline void root_first_candidate(const RootState &S, int i0, int i1, int lane, RootKey *okey, RootRow *orow,
-                                            double *rowout) {
+// the candidate of rows [i0, i1) out of global memory (launch 0, and after the values were worked out afresh):
+// one wave scans them, lane 0 publishes
+__device__ inline void root_first_candidate(const RootState &S, int i0, int i1, bool bland, int lane, RootKey *okey,
+                                            RootRow *orow, double *rowout) {
     const double INF = __builtin_huge_val();
     int blevel = 0, bp = kNoCand, bad = 0;
     double bk = -INF;
@@ -85,6 +86,7 @@ __device__ inline void root_first_candidate(const RootState &S, int i0, int i1, 
             else if (!isinf(up) && a > up + kPTol) { level = 1; viol = a - up; sg = -1; }
         }
         if (level > 0) viol = viol * viol / S.wgt[i];   // dual Devex pricing
+        if (bland && level > 0) { level = 1; viol = 0.0; }
         const int pay = (v << 16) | (sg < 0 ? 0x8000 : 0) | i;
         if (root_better(level, viol, pay, blevel, bk, bp)) { blevel = level; bk = viol; bp = pay; }
     }
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(kRootNT) void lp_root_init(RootState S, const doubl
     while (n2 < n) n2 <<= 1;
     const int PER = n2 / 64;
     // column borders (every workgroup works them out for its beta; the columns j = w (mod G) go to buffer 0)
+    int anyb = 0;
     for (int j = tid; j < n; j += kRootNT) {
         const double lo = S.lo[j], up = S.up[j], dj = c[j];
         int side;
@@ -132,9 +135,10 @@ __global__ __launch_bounds__(kRootNT) void lp_root_init(RootState S, const doubl
         else side = 0;                       // (cold start: no warm-start code says "at upper")
         const double va = side == 0 ? lo : side == 1 ? up : 0.0, vb = side == 2 ? 1.0 : 0.0;
         s_va[j] = va; s_vb[j] = vb;
+        anyb |= side == 2;
         if (j % S.G == w) { S.d[j] = dj; S.nvar[j] = j; S.side[j] = side; S.va[j] = va; S.vb[j] = vb; }
     }
-    __syncthreads();
+    const int sym = __syncthreads_or(anyb);   // (the solve starts with symbolic values: see K1b on what that means for a verdict)
     const int i0 = min(w * S.RPB, m), i1 = min(i0 + S.RPB, m);
     for (int i = i0 + wave; i < i1; i += kRootNT / 64) {
         double *Ti = S.T + (size_t)i * n;
@@ -162,14 +166,73 @@ __global__ __launch_bounds__(kRootNT) void lp_root_init(RootState S, const doubl
         }
         if (lane == 0) {
             const double b0 = -b[i];
-            S.beta0[i] = b0; S.ba[i] = b0 - sa; S.bb[i] = 0.0 - sb; S.wgt[i] = 1.0; S.bvar[i] = n + i;
+            S.beta0[i] = b0; S.ba[i] = b0 - sa; S.bb[i] = snap_m(0.0 - sb); S.wgt[i] = 1.0; S.bvar[i] = n + i;
             S.rlo[i] = 0.0; S.rup[i] = __builtin_huge_val();
         }
     }
     __syncthreads();   // (the rows' new borders are this workgroup's own writes: the barrier orders them for wave 0)
-    if (wave == 0) root_first_candidate(S, i0, i1, lane, S.ckey + w, S.crow + w, S.rowbuf + (size_t)w * n);
+    if (wave == 0) root_first_candidate(S, i0, i1, false, lane, S.ckey + w, S.crow + w, S.rowbuf + (size_t)w * n);
     if (w == 0 && tid == 0) {
-        S.ctl[0] = -1; S.ctl[1] = 0; S.ctl[2] = 0; S.ctl[3] = 0; S.ctl[4] = 0;
+        S.ctl[0] = -1; S.ctl[1] = 0; S.ctl[2] = 0; S.ctl[3] = 0; S.ctl[4] = 0; S.ctl[5] = sym; S.ctl[6] = 1; S.ctl[7] = 0;
+    }
+}
+
+// the values beta = beta0 - T v of every row afresh from the tableau (the host launches this when the status word
+// says -2: a verdict was due on values that thousands of running updates had touched -- the rule of K1b's phase
+// 3).  Same folds as launch 0; the candidates, the column borders and the control words go to parity par ^ 1 like
+// a pivot launch's.
+__global__ __launch_bounds__(kRootNT) void lp_root_values(RootState S, int par) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, w = blockIdx.x;
+    const int m = S.m, n = S.n;
+    double *s_va = (double *)smem_raw, *s_vb = s_va + n;
+    const int *ctl = S.ctl + 8 * par;
+    int *ctl_o = S.ctl + 8 * (par ^ 1);
+    const int cpar = ctl[4] & 1;   // the column borders of the current state
+    const int iters = ctl[1], npiv = ctl[2], degen = ctl[3], sym = ctl[5];
+    int n2 = 64;
+    while (n2 < n) n2 <<= 1;
+    const int PER = n2 / 64;
+    for (int j = tid; j < n; j += kRootNT) {
+        const double va = S.va[(size_t)cpar * n + j], vb = S.vb[(size_t)cpar * n + j];
+        s_va[j] = va; s_vb[j] = vb;
+        if (cpar == par && j % S.G == w) {
+            const size_t a = (size_t)par * n + j, o = (size_t)(par ^ 1) * n + j;
+            S.d[o] = S.d[a]; S.nvar[o] = S.nvar[a]; S.side[o] = S.side[a]; S.va[o] = va; S.vb[o] = vb;
+        }
+    }
+    __syncthreads();
+    const int i0 = min(w * S.RPB, m), i1 = min(i0 + S.RPB, m);
+    for (int i = i0 + wave; i < i1; i += kRootNT / 64) {
+        const double *Ti = S.T + (size_t)i * n;
+        double pa[16], pb[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int j = lane + 64 * k;
+            const bool in = k < PER && j < n;
+            const double t = in ? Ti[j] : 0.0;
+            pa[k] = in ? t * s_va[j] : 0.0;
+            pb[k] = in ? t * s_vb[j] : 0.0;
+        }
+        for (int h = PER / 2; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k < h) { pa[k] = pa[k] + pa[k + h]; pb[k] = pb[k] + pb[k + h]; }
+        }
+        double sa = pa[0], sb = pb[0];
+#pragma unroll
+        for (int h = 32; h >= 1; h >>= 1) {
+            sa = sa + __shfl_down(sa, h, 64);
+            sb = sb + __shfl_down(sb, h, 64);
+        }
+        if (lane == 0) { S.ba[i] = S.beta0[i] - sa; S.bb[i] = snap_m(0.0 - sb); }
+    }
+    __syncthreads();
+    if (wave == 0)
+        root_first_candidate(S, i0, i1, degen > m + n, lane, S.ckey + (size_t)(par ^ 1) * S.G + w, S.crow + (size_t)(par ^ 1) * S.G + w,
+                             S.rowbuf + ((size_t)(par ^ 1) * S.G + w) * n);
+    if (w == 0 && tid == 0) {
+        ctl_o[0] = -1; ctl_o[1] = iters; ctl_o[2] = npiv; ctl_o[3] = degen; ctl_o[4] = par ^ 1; ctl_o[5] = sym; ctl_o[6] = 1; ctl_o[7] = 0;
     }
 }
 
@@ -207,7 +270,7 @@ __global__ __launch_bounds__(kRootNT) void lp_root_pivot(RootState S, int par) {
     RootKey ck;
     ck.viol = -INF; ck.level = 0; ck.pay = kNoCand; ck.bad = 0;
     if (tid < G) ck = S.ckey[(size_t)par * G + tid];
-    const int st = ctl[0], iters = ctl[1], npiv = ctl[2], degen = ctl[3];
+    const int st = ctl[0], iters = ctl[1], npiv = ctl[2], degen = ctl[3], sym = ctl[5], fresh = ctl[6];
     const int i0 = min(w * RPB, m), nr = min(RPB, m - i0);
     double t_[RPB][K];
 #pragma unroll
@@ -241,7 +304,7 @@ __global__ __launch_bounds__(kRootNT) void lp_root_pivot(RootState S, int par) {
         clo_[k] = v < n ? S.lo[v] : 0.0;
         cup_[k] = v < n ? S.up[v] : INF;
     }
-    if (st >= 0) {                // finished in an earlier launch: hand the verdict on
+    if (st != -1) {               // finished in an earlier launch (or waiting for fresh values, -2): hand the word on
         if (w == 0 && tid < 8) ctl_o[tid] = ctl[tid];
         return;
     }
@@ -272,8 +335,12 @@ __global__ __launch_bounds__(kRootNT) void lp_root_pivot(RootState S, int par) {
     } else if ((S.max_iter > 0 && iters >= S.max_iter) || iters >= S.cap) {
         cmd = 4;
     }
-    if (cmd) {   // (ctl[4]: the parity of the column borders that hold the final state)
-        if (w == 0 && tid == 0) { ctl_o[0] = cmd == 1 ? 0 : cmd == 3 ? 2 : 3; ctl_o[1] = iters; ctl_o[2] = npiv; ctl_o[3] = degen; ctl_o[4] = par; }
+    if (cmd) {   // (ctl[4]: the parity of the column borders that hold the final state; -2: fresh values first)
+        const bool want = cmd != 4 && sym && !fresh;
+        if (w == 0 && tid == 0) {
+            ctl_o[0] = want ? -2 : cmd == 1 ? 0 : cmd == 3 ? 2 : 3;
+            ctl_o[1] = iters; ctl_o[2] = npiv; ctl_o[3] = degen; ctl_o[4] = par; ctl_o[5] = sym; ctl_o[6] = fresh; ctl_o[7] = 0;
+        }
         return;
     }
     src = __builtin_amdgcn_readfirstlane(src);
@@ -347,8 +414,11 @@ __global__ __launch_bounds__(kRootNT) void lp_root_pivot(RootState S, int par) {
     }
     __syncthreads();
     const int q = qq;
-    if (q < 0) {   // no entering column: primal infeasible
-        if (w == 0 && tid == 0) { ctl_o[0] = 1; ctl_o[1] = iters; ctl_o[2] = npiv; ctl_o[3] = degen; ctl_o[4] = par; }
+    if (q < 0) {   // no entering column: primal infeasible (on fresh values)
+        if (w == 0 && tid == 0) {
+            ctl_o[0] = (sym && !fresh) ? -2 : 1;
+            ctl_o[1] = iters; ctl_o[2] = npiv; ctl_o[3] = degen; ctl_o[4] = par; ctl_o[5] = sym; ctl_o[6] = fresh; ctl_o[7] = 0;
+        }
         return;
     }
     const int degen_n = s_ci[1];
@@ -383,14 +453,14 @@ __global__ __launch_bounds__(kRootNT) void lp_root_pivot(RootState S, int par) {
         const int i = i0 + lane;
         const double a = s_ac[lane];
         if (i == r) {
-            rb0 = rhon; rba = vaq + ta; rbb = vbq + tb;
+            rb0 = rhon; rba = vaq + ta; rbb = snap_m(vbq + tb);
             const double wn = (wr * pinv) * pinv;
             rwg = wn < 1.0 ? 1.0 : wn;
             rbv = nq; rlo = elo; rup = eup;
             if (wave == 0) { S.bvar[i] = nq; S.rlo[i] = elo; S.rup[i] = eup; }
         } else {
             rb0 = fma(-a, rhon, rb0);
-            rba = fma(-a, ta, rba); rbb = fma(-a, tb, rbb);
+            rba = fma(-a, ta, rba); rbb = snap_m(fma(-a, tb, rbb));
             const double ratio = a * pinv;
             const double wn = (ratio * ratio) * wr;
             rwg = wn > rwg ? wn : rwg;
@@ -409,7 +479,10 @@ __global__ __launch_bounds__(kRootNT) void lp_root_pivot(RootState S, int par) {
             }
         }
     }
-    if (w == 0 && tid == 0) { ctl_o[0] = -1; ctl_o[1] = iters + 1; ctl_o[2] = npiv + 1; ctl_o[3] = degen_n; ctl_o[4] = par ^ 1; }
+    if (w == 0 && tid == 0) {
+        ctl_o[0] = -1; ctl_o[1] = iters + 1; ctl_o[2] = npiv + 1; ctl_o[3] = degen_n; ctl_o[4] = par ^ 1;
+        ctl_o[5] = sym | (lb != 0.0); ctl_o[6] = 0; ctl_o[7] = 0;
+    }
     // ---- E. the candidate for the next launch (every wave works it out; wave 0 publishes) ------------------------
     const bool bland_n = degen_n > m + n;
     int cl = 0, cp = kNoCand, cb = 0;

@@ -163,6 +163,11 @@ int launch_root_coop(mipx_problem *p, mipx::LpArgs &a, hipStream_t stream, bool 
         int32_t st = -1;
         HIP_TRY(ctx, hipMemcpyAsync(&st, S.ctl + 8 * par, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(ctx, hipStreamSynchronize(stream));
+        if (st == -2) {   // a verdict is due on values that carry the running updates of many pivots: afresh from the tableau first
+            hipLaunchKernelGGL(mipx::lp_root_values, dim3(G), dim3(mipx::kRootNT), 2 * nn * 8, stream, S, par);
+            HIP_TRY(ctx, hipGetLastError());
+            par ^= 1;
+        }
         if (st >= 0) break;
     }
     hipLaunchKernelGGL(mipx::lp_root_final, dim3(1), dim3(mipx::kRootNT), nn * 8, stream, S, par, a, (size_t)0);

@@ -193,6 +193,30 @@ def test_one_cold_lp_over_the_chip_statuses(n, m, gpu_ctx, oracle, monkeypatch):
         q.close()
 
 
+@pytest.mark.parametrize('n,m,seed', [(128, 64, 1), (256, 128, 0), (300, 150, 0), (512, 256, 0), (600, 300, 0),
+                                      (1024, 512, 0)])
+def test_infinite_upper_bounds_against_highs_and_the_oracle(n, m, seed, gpu_ctx, oracle, monkeypatch):
+    """u = +inf everywhere (values a + b M carried through thousands of pivots; see
+    tests/test_oracle_known_answers.py::test_infinite_upper_bounds_match_highs): every kernel -- K1, K1c (one
+    cold LP), K1b (the same LP twice in a batch, and with MIPX_NO_COOP_ROOT) -- ends optimal on HiGHS's
+    objective to 1e-9 and on the oracle's bits."""
+    from scipy.optimize import linprog
+    A, b, c, l, _, _ = random_dense_milp_arrays(n, m, seed=seed)
+    u = np.full(n, INF)
+    want = oracle.lp_solve_batch(A, b, c, l[None], u[None])
+    h = linprog(c, A_ub=-A, b_ub=-b, bounds=[(lo, None) for lo in l], method='highs')
+    p = _ffi.Problem(gpu_ctx, A, b, c)
+    g = p.solve_batch(l[None], u[None])
+    assert_same(g, want, 'one cold LP')
+    assert g['status'][0] == 0 and abs(g['obj'][0] - h.fun) <= 1e-9 * abs(h.fun)
+    two = p.solve_batch(np.stack([l, l]), np.stack([u, u]))
+    for k in range(2):
+        assert_same({q: v[k:k + 1] for q, v in two.items()}, want, f'batch of two, node {k}')
+    monkeypatch.setenv('MIPX_NO_COOP_ROOT', '1')
+    assert_same(p.solve_batch(l[None], u[None]), want, 'one workgroup')
+    p.close()
+
+
 def test_s5_shape_1024x512(gpu_ctx, oracle):
     """BASELINE config C5 shape: 1024 vars x 512 rows.  The cold root needs tens of thousands of
     pivots, so parity is checked on truncated solves (every state after k pivots must agree) and on

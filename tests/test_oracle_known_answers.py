@@ -66,6 +66,25 @@ def test_objective_matches_highs(oracle, n, m, seed):
     assert np.all(A @ r['x'] >= b - 1e-6) and np.all(r['x'] >= l - 1e-9) and np.all(r['x'] <= u + 1e-9)
 
 
+@pytest.mark.parametrize('n,m,seed', [(64, 32, 0), (128, 64, 1), (256, 128, 0), (256, 128, 3), (300, 150, 0),
+                                      (512, 256, 0), (600, 300, 0), (1024, 512, 0)])
+def test_infinite_upper_bounds_match_highs(oracle, n, m, seed):
+    """u = +inf for every variable: the cold solve starts with nonbasic variables at the symbolic bound M and
+    carries values a + b M for thousands of pivots.  Round 3 found two faults here, invisible to GPU == oracle
+    tests: the report multiplied rounding noise left in b by 1e10 (objective off by 1e-5 relative from 128 x 64
+    on), and from 512 x 256 on the noise grew past the zero tolerance -- the solve chased symbolic violations
+    that were not there until the iteration cap (status 3), or ended 'infeasible'.  Pinned against HiGHS to
+    1e-9: b is cleared below the tolerance at every update, and above the register tiles a verdict is taken
+    on values worked out afresh from the tableau."""
+    A, b, c, l, _, _ = random_dense_milp_arrays(n, m, seed=seed)
+    u = np.full(n, INF)
+    r = oracle.lp_solve(A, b, c, l, u)
+    h = linprog(c, A_ub=-A, b_ub=-b, bounds=[(lo, None) for lo in l], method='highs')
+    assert r['status'] == 0 and h.status == 0
+    assert abs(r['obj'] - h.fun) <= 1e-9 * max(1, abs(h.fun))
+    assert np.all(A @ r['x'] >= b - 1e-6) and np.all(r['x'] >= l - 1e-9)
+
+
 def test_example_models_lp_relaxations_match_highs(oracle):
     from simple_mip_solver_amd.milp_instance import read_mps
     here = os.path.dirname(__file__)
