@@ -313,6 +313,7 @@ struct mipx_tree {
     hipStream_t stf = nullptr;  // device finish: the finish kernels of step k and the table's version chain, beside the node LPs of step k+1
     hipEvent_t ev_child = nullptr;
     bool child_pending = false;
+    bool cold_launch = false;       // the next launch_lp is the root's first solve (LpArgs::cold)
     int32_t *h_pairs = nullptr; // pinned staging of the branching lists
     char *h_pres = nullptr;     // pinned mirror of the probe results [pp_obj | pp_status]
     StepBuf buf[3];   // a ring: up to three steps in flight (mipx_tree_solve)
@@ -494,6 +495,8 @@ int launch_lp(mipx_tree *t, int batch, const double *l, const double *u, const i
     a.A = t->prob->dA; a.b = t->prob->db; a.c = t->prob->dc;
     a.A_stride = a.b_stride = a.c_stride = 0;
     a.l = l; a.u = u; a.vstat_in = v; a.slot = slot; a.max_iter = max_iter;
+    a.cold = t->cold_launch ? 1 : 0;   // (the root's step: its pool row holds no basis)
+    t->cold_launch = false;
     a.anchor_T = t->prob->anchor_on ? t->prob->anchor_T : nullptr;
     a.anchor_vec = t->prob->anchor_on ? t->prob->anchor_vec : nullptr;
     a.anchor_idx = t->prob->anchor_on ? t->prob->anchor_idx : nullptr;
@@ -807,6 +810,8 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
         return MIPX_OK;
     }
     HIP_TRY(ctx, hipEventRecord(S.e0, st));
+    // the root alone, never solved: one cold LP (above the register tiles it is spread over the chip, K1c)
+    t->cold_launch = B == 1 && t->nodes.size() == 1 && S.recs[0].depth == 0 && S.recs[0].b_idx == -1 && !t->prob->anchor_on;
     rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, S.d_slot, 0, S.d_status, S.d_obj,
                    S.d_x, S.d_vout, S.d_iters, S.d_npiv, nullptr, S.dive ? &S : nullptr, S.d_slot + B);
     if (rc) return rc;
