@@ -100,4 +100,6 @@ if fe and wr:
     print(json.dumps(k1b))
 if glob.glob(O + '/c4_trace/*/*kernel_trace.csv'):
     by_grid(O + '/c4_trace', O + f'/{TAG}_c4_kernel_by_grid.csv')
+if glob.glob(O + '/k1c_trace/*/*kernel_trace.csv'):
+    by_grid(O + '/k1c_trace', O + f'/{TAG}_k1c_kernel_by_grid.csv')
 print(open(O + f'/{TAG}_kernel_by_grid.csv').read()[:3000])

@@ -29,4 +29,7 @@ echo k1b done
 # C4 (cut rounds in the engine): kernel trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_trace -- python3 $R/scripts/c4_tree.py 256 128 4096 10 > $O/c4_trace.log 2>&1
 echo c4 done
+# K1c (one cold 1024 x 512 LP over the chip, one launch per pivot): kernel trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/k1c_trace -- python3 $R/scripts/root_coop.py 1024 512 > $O/k1c_trace.log 2>&1
+echo k1c done
 python3 $R/scripts/collect_profiles.py $O
