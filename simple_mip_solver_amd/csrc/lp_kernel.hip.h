@@ -121,7 +121,7 @@ constexpr int kDseRefresh = 64;   // iterations after which the steepest-edge we
 #define KPROF_MARK(k) do { } while (0)
 #endif
 // MIPX_KPROF_OUT: the slots of the refactorisation marks time the output section instead
-#if defined(MIPX_KPROF_RT)   /* ... or the stages of the ratio test (per iteration) */
+#if defined(MIPX_KPROF_RT) || defined(MIPX_KPROF_SETUP)   /* ... or the stages of the ratio test (per iteration), or of the set-up */
 #define KPROF_REF_MARK(k) do { } while (0)
 #define KPROF_OUT_MARK(k) do { } while (0)
 #elif defined(MIPX_KPROF_OUT)
@@ -1417,6 +1417,117 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     __syncthreads();
     tprev = clock64();   // (the dump above is the profiler's own cost)
 #endif
+    // The engine's steps want neither row duals nor a tableau dump: then everything below is the control
+    // wave's alone -- it holds both borders in registers -- and the tableau waves go straight to the barrier
+    // behind which the dive's decision is known.  (The general path hands the borders over through LDS and
+    // shares the loops out: three more barriers, each with a serial stretch before it.)  Same arithmetic,
+    // same order: x by variable index, the objective's fold-in-half sum, K4's rule.
+    if (g.y == nullptr && g.dbg_T == nullptr) {
+    const bool more = DIVE && pass < g.dive && solve;  // (DIVE = false: the pass loop folds away)
+    if (ctl) {
+        constexpr int PER = NP / 64;
+        static_assert(PER == PJ, "one column per lane and slot");
+#pragma unroll
+        for (int kk = 0; kk < PJ; kk++) {
+            const int j = lane + 64 * kk;
+            const int v = cM[kk] >> 3, sd = cM[kk] & 3;
+            if (j >= n) s.key[j] = 0.0;   // (the padding of the fold; columns >= n hold no variable)
+            if (j < n && v < n) s.key[v] = sd == 2 ? kMReport : s.va[j];
+        }
+#pragma unroll
+        for (int kk = 0; kk < PI; kk++) {
+            const int i = lane + 64 * kk;
+            const int v = rM[kk] >> 2;
+            if (i < m && v < n) s.key[v] = fma(rBb[kk], kMReport, rBa[kk]);
+        }
+        if (g.vstat_out) {   // the basis, straight from the registers
+            int8_t *vo = g.vstat_out + onode * (size_t)(n + ms);
+#pragma unroll
+            for (int kk = 0; kk < PI; kk++)
+                if (lane + 64 * kk < m) vo[rM[kk] >> 2] = 1;
+#pragma unroll
+            for (int kk = 0; kk < PJ; kk++)
+                if (lane + 64 * kk < n) vo[cM[kk] >> 3] = (cM[kk] & 3) ? 2 : 3;
+        }
+        // (one wave: its LDS writes above are in order before the reads below)
+        double p[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int j = lane + 64 * k;
+            const double xj = s.key[j];
+            if (g.x && j < n) g.x[onode * n + j] = xj;
+            p[k] = j < n ? s.cvec[j] * xj : 0.0;
+        }
+#pragma unroll
+        for (int h = PER / 2; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int k = 0; k < h; k++) p[k] = p[k] + p[k + h];
+        }
+        double sum = p[0];
+        sum = sum + xor32_f64(sum);
+        sum = sum + swz16_f64(sum);
+        sum = sum + xor8_f64(sum);
+        sum = sum + xor4_f64(sum);
+        sum = sum + xor2_f64(sum);
+        sum = sum + xor1_f64(sum);
+        const double objv = uniform_f64(sum);
+        int code = -1;
+        double dval = 0.0;
+        if (more && status == 0 && objv < g.dive_cutoff) {
+            double bk = -1.0;
+            int bp = kNoCand, nprobe = 0;
+#pragma unroll
+            for (int kk = 0; kk < PJ; kk++) {
+                const int k = lane + 64 * kk;
+                const double v = s.key[ci[kk]];
+                const double fl = floor(v), ce = ceil(v);
+                const double dist = fmin(v - fl, ce - v);
+                const bool frac = cv[kk] && dist > kVarEps;
+                const double key = g.rule == 0 ? dist : fmin(ccr[kk] * (ce - v), ccl[kk] * (v - fl));
+                keep_max(bk, bp, key, k, frac && che[kk]);
+                nprobe += __popcll(__ballot(frac && !che[kk]));
+            }
+            double km;
+            const int win = wave_argmax_pos(bk, bp, km);
+            if (win != kNoCand && nprobe == 0) {
+                const int wl = win & 63, wk = win >> 6;
+                int t_i;
+                double t_l, t_r;
+                MIPX_PICK(t_i, ci, PJ, wk);
+                MIPX_PICK(t_l, ccl, PJ, wk);
+                MIPX_PICK(t_r, ccr, PJ, wk);
+                dvar = __builtin_amdgcn_readlane(t_i, wl);
+                const double wcl = readlane_f64(t_l, wl), wcr = readlane_f64(t_r, wl);
+                const double v = uniform_f64(s.key[dvar]);
+                const double fl = floor(v), ce = ceil(v);
+                if (g.rule == 0) ddir = (v - fl <= ce - v) ? 0 : 1;
+                else ddir = (wcl * (v - fl) <= wcr * (ce - v)) ? 0 : 1;
+                dbound = ddir == 0 ? fl : ce;
+                dval = v;
+                bool mine = false;  // a bound change in place needs the variable basic
+#pragma unroll
+                for (int kk = 0; kk < PI; kk++) mine |= (lane + 64 * kk < m) && (rM[kk] >> 2) == dvar;
+                if (__ballot(mine) != 0ull) code = dvar;
+            }
+        }
+        if (lane == 0) {
+            if (g.obj) g.obj[onode] = status == 1 ? INF : objv;
+            if (g.status) g.status[onode] = status;
+            if (g.iters) g.iters[onode] = iters;
+            if (g.npivots) g.npivots[onode] = npiv;
+            if (code >= 0) {
+                const size_t di = (size_t)pass * (size_t)g.dive_off + node;
+                g.dive_var[di] = dvar;
+                g.dive_dir[di] = ddir;
+                g.dive_val[di] = dval;
+            }
+            s.dive_code = code;
+        }
+    }
+    if (!more) break;
+    KPROF_OUT_MARK(14);
+    __syncthreads();
+    } else {
     if (ctl) {
         // the borders go to LDS for the output loops; x by variable index (s.key) straight from the registers
 #pragma unroll
@@ -1576,6 +1687,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     if (!more) break;
     KPROF_OUT_MARK(14);
     __syncthreads();
+    }
     }
     if (__builtin_amdgcn_readfirstlane(s.dive_code) < 0) break;
     KPROF_MARK(11);  // outputs of the node + the branching rule
