@@ -206,10 +206,13 @@ constexpr int kGomoryGroup = 8;
 inline size_t gomory_lds_bytes(int n, int ms, int group) {
     return ((size_t)group * (n + ms) + ms + 128) * 8 + (3 * (size_t)ms + n) * 4 + 64;
 }
-// the largest group whose staging fits 48 KiB of LDS
-inline int gomory_group(int n, int ms) {
+// the largest group whose staging fits the LDS a workgroup may take: 48 KiB where several workgroups should
+// share a CU; with no more workgroups than CUs (few nodes of a large shape: 1024 x 512 stages 12.5 KiB per cut)
+// most of the CU's 160 KiB -- a group of 8 walks the rows of A 4 x less often than a group of 2
+inline int gomory_group(int n, int ms, long workgroups = 1 << 30) {
+    const size_t cap = workgroups <= 256 ? 144 * 1024 : workgroups <= 512 ? 72 * 1024 : 48 * 1024;
     int grp = kGomoryGroup;
-    while (grp > 1 && gomory_lds_bytes(n, ms, grp) > 48 * 1024) grp--;
+    while (grp > 1 && gomory_lds_bytes(n, ms, grp) > cap) grp--;
     return grp;
 }
 

@@ -780,10 +780,12 @@ int mipx_gomory_batch(mipx_problem *p, int batch, const double *l, const double 
         g.ncuts = (int32_t *)(base + o_nc); g.row_idx = (int32_t *)(base + o_ri);
         g.pi = (double *)(base + o_pi); g.pi0 = (double *)(base + o_p0);
         g.safe_pi = (double *)(base + o_sp); g.safe_pi0 = (double *)(base + o_s0);
-        g.group = mipx::gomory_group(p->n, p->m);
+        g.chunks = batch >= 256 ? 1 : (batch >= 32 ? 4 : 16);  // (enough workgroups to use the GPU either way)
+        g.group = mipx::gomory_group(p->n, p->m, (long)batch * g.chunks);
         g.mfma = (getenv("MIPX_K2_MFMA") && atoi(getenv("MIPX_K2_MFMA"))) ? 1 : 0;   // (experiment: cut_kernels.hip.h)
         const size_t lds = mipx::gomory_lds_bytes(p->n, p->m, g.group);
-        g.chunks = batch >= 256 ? 1 : (batch >= 32 ? 4 : 16);  // (enough workgroups to use the GPU either way)
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)mipx::gomory_cuts<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            rc = fail(ctx, MIPX_EHIP, "mipx_gomory_batch: LDS size");
         hipLaunchKernelGGL((mipx::gomory_cuts<256>), dim3(batch * g.chunks), dim3(256), lds, st, g);
         if (hipGetLastError() != hipSuccess) rc = fail(ctx, MIPX_EHIP, "mipx_gomory_batch: launch");
     }

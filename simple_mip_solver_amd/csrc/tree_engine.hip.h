@@ -892,10 +892,12 @@ int tree_cut_rounds(mipx_tree *t, StepBuf &S) {
         ga.active = S.cs_active;
         ga.slab_pi = S.slab_pi; ga.slab_pi0 = S.slab_pi0;
         ga.slab_n = S.cs_state + (size_t)mipx::CF_SLAB_N * B; ga.slab_rows = t->slab_rows;
-        ga.group = mipx::gomory_group(n, t->mrows);
+        ga.group = mipx::gomory_group(n, t->mrows, (long)B * ga.chunks);
         ga.mfma = (std::getenv("MIPX_K2_MFMA") && std::atoi(std::getenv("MIPX_K2_MFMA"))) ? 1 : 0;   // (experiment: cut_kernels.hip.h)
         const size_t lds2 = mipx::gomory_lds_bytes(n, t->mrows, ga.group);
         HIP_TRY(ctx, hipEventRecord(S.k2a, st));
+        if (lds2 > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute((const void *)mipx::gomory_cuts<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL((mipx::gomory_cuts<256>), dim3(B * ga.chunks), dim3(256), lds2, st, ga);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(S.k2b, st));
