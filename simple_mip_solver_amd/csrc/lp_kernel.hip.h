@@ -104,7 +104,7 @@ struct LpArgs {
     const double *cut_pi = nullptr, *cut_pi0 = nullptr;
     int cut_stride = 0, mstride = 0, vstat_by_node = 0;
     const int32_t *active = nullptr;  // optional: node k is skipped (nothing read or written) where active[k] == 0
-    int cold = 0;                     // the caller vouches that vstat_in holds no basis (all codes 0): a cold start (K1c may take it)
+    int cold = 0;                     // the caller vouches that vstat_in holds no basis (all codes 0) and the nodes no cut row: a cold start (K1c may take it)
 };
 
 constexpr double kVarEps = 1e-4;  // utils/tolerance.py:2 variable_epsilon

@@ -113,8 +113,9 @@ int launch_root_coop(mipx_problem *p, mipx::LpArgs &a, hipStream_t stream, bool 
     *done = false;
     mipx_ctx *ctx = p->ctx;
     const int m = p->m, n = p->n;
-    if (a.batch != 1 || (a.vstat_in != nullptr && !a.cold) || a.ncut != nullptr || a.refactor_only || m < 64 || n > mipx::kBigMaxN ||
-        a.A_stride != 0 || (a.dbg_T && a.dbg_all) || (getenv("MIPX_NO_COOP_ROOT") && atoi(getenv("MIPX_NO_COOP_ROOT"))))
+    // (LpArgs::cold: no basis and no cut row, whatever vstat_in / ncut point to; one node: a dump of "every node" is node 0's)
+    if (a.batch != 1 || ((a.vstat_in != nullptr || a.ncut != nullptr) && !a.cold) || a.refactor_only || m < 64 || n > mipx::kBigMaxN ||
+        a.A_stride != 0 || (getenv("MIPX_NO_COOP_ROOT") && atoi(getenv("MIPX_NO_COOP_ROOT"))))
         return MIPX_OK;
     int32_t src = 0;
     if (a.slot) {

@@ -801,6 +801,8 @@ int tree_launch(mipx_tree *t, StepBuf &S, int want) {
             cl.dT = S.dump_T; cl.dvec = S.dump_vec; cl.didx = S.dump_idx;
         }
         HIP_TRY(ctx, hipEventRecord(S.e0, st));
+        t->cold_launch = B == 1 && t->nodes.size() == 1 && S.recs[0].depth == 0 && S.recs[0].b_idx == -1 && S.recs[0].ncut == 0 &&
+                         !t->prob->anchor_on;   // (the root alone, never solved, no cut yet: one cold LP)
         rc = launch_lp(t, B, t->pool_l, t->pool_u, t->pool_v, S.d_slot, 0, S.d_status, S.d_obj, S.d_x,
                        S.d_vout, S.d_iters, S.d_npiv, nullptr, nullptr, S.d_slot + B, &cl);
         if (rc) return rc;
