@@ -614,13 +614,12 @@ struct RowArr {
 // largest violation (violations of the symbolic bound M first), ties -> lowest variable index
 #define MIPX_LEAVE_SELECT()                                                                  \
     do {                                                                                     \
-        int blevel = 0, bp = kNoCand;                                                            \
-        double bk = -1.0;                                                                        \
-        bool anybb = false, anym = false;                                                        \
-_Pragma("unroll")                                                                                \
-        for (int kk = 0; kk < PI; kk++) anym |= (lane + 64 * kk < m) & (fabs(rBb[kk]) > kBTol);  \
-        if (!__ballot(anym)) {                                                                   \
-            /* the usual case, no symbolic-M part anywhere: plain bound violations */            \
+        int cmd = 0, win = 0;                                                                    \
+        if (!symU) {                                                                             \
+            /* the usual case, no symbolic-M part anywhere (symU, a scalar, says so: no ballot): */  \
+            /* plain bound violations; no candidate in any lane = the end of the solve */        \
+            int bp = kNoCand;                                                                    \
+            double bk = -1.0;                                                                    \
 _Pragma("unroll")                                                                                \
             for (int kk = 0; kk < PI; kk++) {                                                    \
                 const int i = lane + 64 * kk;                                                    \
@@ -632,8 +631,14 @@ _Pragma("unroll")                                                               
                 const int pay = ((rM[kk] >> 2) << 16) | (lowv ? 0 : 0x8000) | i;                 \
                 keep_max(bk, bp, viol, pay, (i < m) & (lowv | upv));                             \
             }                                                                                    \
-            blevel = bp != kNoCand ? 1 : 0;                                                      \
+            double km;                                                                           \
+            win = wave_argmax_pos(bk, bp, km);                                                   \
+            if (win == kNoCand) cmd = nfk > 0 ? 3 : 1;                                           \
+            else if ((g.max_iter > 0 && iters >= g.max_iter) || iters >= cap) cmd = 4;           \
         } else {                                                                                 \
+            int blevel = 0, bp = kNoCand;                                                        \
+            double bk = -1.0;                                                                    \
+            bool anybb = false;                                                                  \
 _Pragma("unroll")                                                                                \
             for (int kk = 0; kk < PI; kk++) {                                                    \
                 const int i = lane + 64 * kk;                                                    \
@@ -662,16 +667,15 @@ _Pragma("unroll")                                                               
                     if (up_lvl || same) { blevel = level; bk = viol; bp = pay; }                 \
                 }                                                                                \
             }                                                                                    \
-        }                                                                                        \
-        const int lvl = __ballot(blevel == 2) ? 2 : (__ballot(blevel == 1) ? 1 : 0);             \
-        int cmd = 0, win = 0;                                                                    \
-        if (lvl == 0) {                                                                          \
-            cmd = (__ballot(anybb) || nfk > 0) ? 3 : 1;                                          \
-        } else if ((g.max_iter > 0 && iters >= g.max_iter) || iters >= cap) {                    \
-            cmd = 4;                                                                             \
-        } else {                                                                                 \
-            double km;                                                                           \
-            win = wave_argmax_pos(bk, blevel == lvl ? bp : kNoCand, km);                         \
+            const int lvl = __ballot(blevel == 2) ? 2 : (__ballot(blevel == 1) ? 1 : 0);         \
+            if (lvl == 0) {                                                                      \
+                cmd = (__ballot(anybb) || nfk > 0) ? 3 : 1;                                      \
+            } else if ((g.max_iter > 0 && iters >= g.max_iter) || iters >= cap) {                \
+                cmd = 4;                                                                         \
+            } else {                                                                             \
+                double km;                                                                       \
+                win = wave_argmax_pos(bk, blevel == lvl ? bp : kNoCand, km);                     \
+            }                                                                                    \
         }                                                                                        \
         /* the choice goes out at once; the border values of row r follow after barrier A */      \
         sel_win = cmd == 0 ? (win & 0xffff) : (cmd << 16);                                       \
@@ -1155,6 +1159,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
     int pass = 0;
     asm volatile("" : "+s"(pass));  // opaque: keeps the compiler from peeling the first pass (two copies of the sweep)
     size_t onode = (size_t)node;
+    bool symU = false;           // control wave: some basic value may carry a symbolic part (MIPX_LEAVE_SELECT)
     int dvar = -1, ddir = 0;     // control wave: the dive's branching variable, direction,
     double dbound = 0.0;         //   and the bound that moves (floor / ceil of its value)
     int wage = 0;                // iterations since the steepest-edge weights were exact (both roles count)
@@ -1171,6 +1176,9 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
             int degen = 0;  // consecutive degenerate steps; > m+n -> Bland's rule
             const int nfk0 = nfake;
             int nfk = nfk0;
+            // may a basic value carry a symbolic part?  Only once a nonbasic variable has sat at the symbolic bound
+            // (then it stays true for the solve: the general selection gives the same answer where none does)
+            if (pass == 0) symU = nfake != 0;
             double dje[PJ], cN[PJ];  // per column, for the ratio test: max(+-d, 0), that + tol,
             unsigned cS[PJ];         //   the sign mask of an eligible entry,
             int cP[PJ];              //   the payload (variable << 16 | column)
@@ -1286,6 +1294,7 @@ __device__ __forceinline__ void lp_dual_simplex_role(const LpArgs &g, Smem<NW, R
                     degen = djq <= kDTol ? degen + 1 : 0;
                     bland = degen > m + n;
                     nfk += ((lvmeta & 3) == 2 ? 1 : 0) - ((cm & 3) == 2 ? 1 : 0);
+                    symU |= ((lvmeta & 3) == 2) | ((cm & 3) == 2);
                     ev = cm >> 3;
                     vaq = uniform_f64(s.va[qq]);
                     vbq = uniform_f64(s.vb[qq]);
