@@ -15,9 +15,12 @@
 //   E. leaves its best leaving-row candidate (+ that row) for the next launch.
 // Same arithmetic per element and the same selection rules (lexicographic: level, priced violation, payload)
 // as K1b / the oracle -- dual Devex pricing, Harris two-pass ratio test, Bland after m + n degenerate steps,
-// fold-in-half sums -- so the results are bit-identical to K1b's for the same LP (tests/test_lp_kernel_gpu.py).
+// fold-in-half sums, the symbolic component cleared below its tolerance at every update -- so the results are
+// bit-identical to K1b's for the same LP (tests/test_lp_kernel_gpu.py).  A verdict of a solve that has carried
+// symbolic values is taken on values worked out afresh from the tableau, as in K1b: the pivot launch leaves the
+// status word -2 and the host puts lp_root_values in between.
 // Cold starts only (no warm-start basis, no cut rows, no dive): the engine uses it for the root of shapes above
-// the register tiles.
+// the register tiles; mipx_lp_solve_batch for a single node without a basis.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,7 +29,7 @@
 
 namespace mipx {
 
-constexpr int kRootNT = 256;      // threads per workgroup (the ratio test of K1b runs on 256 threads too)
+constexpr int kRootNT = 256;      // threads per workgroup: thread t holds columns t + 256 k (n <= 1024), and one candidate of <= 256
 
 struct RootKey {                  // a workgroup's best leaving row: what the choice between workgroups compares
     double viol;                  // priced violation (Bland: 0)

@@ -45,6 +45,7 @@ struct mipx_problem {
     int big_slabs2 = 0;
     int big_rows = 0;                 // rows per slab (m, or m + cut rows once a launch carried them)
     char *root_state = nullptr;       // K1c (one cold LP over the chip): its buffers, allocated on first use
+    size_t root_state_bytes = 0;
     // anchor tableau (mipx_problem_set_anchor): warm starts refactor from it
     double *anchor_T = nullptr, *anchor_vec = nullptr;
     int32_t *anchor_idx = nullptr;
@@ -138,7 +139,12 @@ int launch_root_coop(mipx_problem *p, mipx::LpArgs &a, hipStream_t stream, bool 
                  o_vb = carve(2 * nn * 8), o_nv = carve(2 * nn * 4), o_sd = carve(2 * nn * 4),
                  o_ck = carve(2 * (size_t)G * sizeof(mipx::RootKey)), o_cr = carve(2 * (size_t)G * sizeof(mipx::RootRow)), o_row = carve(2 * (size_t)G * nn * 8),
                  o_ctl = carve(16 * 4);
-    if (!p->root_state) HIP_TRY(ctx, hipMalloc((void **)&p->root_state, off));
+    if (p->root_state_bytes < off) {   // (the size depends on the number of workgroups: MIPX_ROOT_WG may have changed)
+        if (p->root_state) (void)hipFree(p->root_state);
+        p->root_state = nullptr; p->root_state_bytes = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&p->root_state, off));
+        p->root_state_bytes = off;
+    }
     char *base = p->root_state;
     mipx::RootState S;
     S.m = m; S.n = n; S.G = G; S.RPB = RPB;
