@@ -262,7 +262,9 @@ def two_phase(ctx, A, b, c, l, u, ints, dive, dfs_seconds, limit, pool_log2, mip
     t.set_anchor_mode(True)
     t.set_dive(max(1, dive))
     first, s = None, None
-    while time.perf_counter() - t0 < dfs_seconds:
+    # (at least one call: on a box where allocating the pool above takes longer than the phase, the clock has
+    # already run out here)
+    while s is None or time.perf_counter() - t0 < dfs_seconds:
         s = t.solve(mip_gap=mip_gap, frontier_batch=1024, max_steps=2 if first is None else 20)
         if first is None and s['primal_bound'] < inf:
             first = {'seconds': time.perf_counter() - t0, 'nodes': s['evaluated_nodes'], 'objective': s['primal_bound']}
@@ -280,7 +282,8 @@ def two_phase(ctx, A, b, c, l, u, ints, dive, dfs_seconds, limit, pool_log2, mip
         t.set_dive(max(1, dive))
         if pb < inf:
             t.set_primal_bound(pb)
-        while time.perf_counter() - t0 < limit:
+        s = None
+        while s is None or time.perf_counter() - t0 < limit:
             s = t.solve(mip_gap=mip_gap, frontier_batch=8192, max_steps=10)
             note(s, nodes)
             if s['status'] != 4 or s['pool_exhausted']:
@@ -565,7 +568,12 @@ def main():
     # at the barrier below)
     cpu, sample = None, None
     if rank == 0 and args.cpu_seconds > 0:
-        cpu, sample = cpu_port_baseline(args, tree, A, b, c, l, u, ints, B)
+        try:
+            cpu, sample = cpu_port_baseline(args, tree, A, b, c, l, u, ints, B)
+        except Exception as e:   # noqa: BLE001 -- a reported baseline, never worth the measurement (or a hang of the other ranks)
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            cpu, sample = {'error': f'cpu_port_baseline failed: {type(e).__name__}: {e}'}, None
 
     before = tree.stats()
     barrier()
@@ -607,16 +615,24 @@ def main():
                 traffic = None
         hbm_gbps = None if (traffic is None or stale) else traffic / launch_s / 1e9
         tree.close()   # (its node pool -- up to 160 GB -- makes room for the legs below)
-        nodive = no_dive_leg(args, ctx, prob, l, u, ints, B) if (world == 1 and args.dive and args.no_dive_leg) else None
-        tto = time_to_optimal_leg(args, ctx, A, b, c, l, u, ints) if args.tto_seconds > 0 and (n, m) == (256, 128) else None
-        tto_small = largest_closing_time_to_optimal(ctx, args.dive) if args.tto_seconds > 0 else None
-        highs = highs_baseline(args, prob, A, b, c, sample) if (sample is not None and args.highs_seconds > 0) else None
-        others = other_configs(args, ctx) if args.others else None
+        def leg(name, fn, *a):
+            """A side leg of the line (never the timed region): if it fails, the line still goes out and says so."""
+            try:
+                return fn(*a)
+            except Exception as e:   # noqa: BLE001 -- reported, not hidden
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                return {'error': f'{name} failed: {type(e).__name__}: {e}'}
+        nodive = leg('no_dive_leg', no_dive_leg, args, ctx, prob, l, u, ints, B) if (world == 1 and args.dive and args.no_dive_leg) else None
+        tto = leg('time_to_optimal_leg', time_to_optimal_leg, args, ctx, A, b, c, l, u, ints) if args.tto_seconds > 0 and (n, m) == (256, 128) else None
+        tto_small = leg('largest_closing_time_to_optimal', largest_closing_time_to_optimal, ctx, args.dive) if args.tto_seconds > 0 else None
+        highs = leg('highs_baseline', highs_baseline, args, prob, A, b, c, sample) if (sample is not None and args.highs_seconds > 0) else None
+        others = leg('other_configs', other_configs, args, ctx) if args.others else None
         out = {
             'metric': 'node LP-relaxations/s', 'value': lps_total / elapsed_max,
             'unit': 'node LP-relaxations/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed_max / args.steps * 1e3,
-            'value_no_dive': None if nodive is None else nodive['value'], 'no_dive': nodive,
+            'value_no_dive': None if nodive is None else nodive.get('value'), 'no_dive': nodive,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic' + (' (REHEARSAL: ranks share GPUs, gloo transport -- not a measurement)' if rehearsal else ''),
             'config': {
