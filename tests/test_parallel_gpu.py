@@ -296,3 +296,22 @@ def test_two_processes_share_the_gpu_rehearsal(tmp_path):
     res = run_two_ranks(script, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-6000:]
     assert 'rank0ok' in res.stdout and 'rank1ok' in res.stdout
+
+
+def test_bench_with_four_ranks_rehearsal():
+    """`bench.py --gpus 4` as the driver launches it, rehearsed on the one GPU of the box: four processes share the
+    card, the exchange protocol runs over the test transport (RCCL refuses several ranks on one device).  Never a
+    measurement -- the line says so -- but every rank goes through the replicated ramp-up, the sharding, the
+    pipelined all-gathers of four records and the joint bookkeeping of the timed region, and rank 0's line comes
+    out."""
+    import json
+    env = dict(os.environ, MIPX_BENCH_TRANSPORT='gloo')
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '12', '--warmup', '2',
+                          '--batch', '512', '--exchange-every', '3', '--cpu-seconds', '0', '--highs-seconds', '0',
+                          '--tto-seconds', '0', '--others', '0', '--no-dive-leg', '0'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 4 and line['steps'] == 12 and 'REHEARSAL' in line['data']
+    assert line['config']['exchanges'] >= 3 and line['value'] > 0
+    assert line['config']['open_nodes_total'] > 4 * 512
